@@ -1,0 +1,297 @@
+/*
+ * ptgpu.h — C ABI of the MI355X path-tracing integrator (libptgpu.so).
+ *
+ * This is the drop-in boundary for the per-pixel sampling hot path of
+ * flomonster/path-tracer.  The reference has no FFI; the narrowest seam is
+ *
+ *     Renderer::new(&RenderConfig, Profile)            src/renderer/mod.rs:61-73
+ *     Renderer::render(&self, &Scene) -> RgbImage      src/renderer/mod.rs:76-169
+ *
+ * called from run_render (src/main.rs:46-47) and the golden-image test helper
+ * (src/main.rs:79).  A Rust host would bind exactly the functions declared
+ * here (see INTEGRATION.md for the `extern "C"` block); the C++ host in
+ * path-tracer_amd/host/ uses them the same way.
+ *
+ * Everything is plain C: POD structs, pointers and sizes.  The caller owns all
+ * host buffers; the library copies the scene to the device in
+ * pt_scene_create() and owns device memory until pt_scene_destroy().
+ *
+ * All functions return 0 on success and a negative pt_status on failure;
+ * pt_last_error() returns a thread-local message (the CLI maps any failure to
+ * exit code 2 like src/main.rs:14-22).
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* status codes                                                        */
+/* ------------------------------------------------------------------ */
+enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,   /* bad argument / malformed scene            */
+    PT_ERR_IO = -2,        /* file could not be read / written          */
+    PT_ERR_PARSE = -3,     /* JSON / YAML / PNG syntax                  */
+    PT_ERR_DEVICE = -4,    /* HIP runtime failure, no GPU               */
+    PT_ERR_NUMERIC = -5,   /* NaN hit distance etc. (reference panics:  */
+                           /* src/renderer/utils.rs:19)                 */
+    PT_ERR_UNSUPPORTED = -6
+};
+
+/* ------------------------------------------------------------------ */
+/* scene description: flat mirror of src/scene/internal/{mod,model,    */
+/* material,light,camera,vertex,triangle}.rs                           */
+/* ------------------------------------------------------------------ */
+
+enum { PT_MODEL_MESH = 0, PT_MODEL_SPHERE = 1 };     /* internal/model.rs:10-21 */
+enum { PT_LIGHT_POINT = 0, PT_LIGHT_DIRECTIONAL = 1 }; /* internal/light.rs:6-17 */
+enum { PT_BRDF_COOK_TORRANCE = 0 };                  /* renderer/brdf/mod.rs:50-55 */
+enum { PT_TONEMAP_REINHARD = 0, PT_TONEMAP_FILMIC = 1, PT_TONEMAP_ACES = 2 }; /* tonemap.rs:5-13 */
+
+/* One decoded texture (image crate: into_rgb8() → 3 channels,
+ * into_luma8() → 1 channel; internal/texture_bank.rs:21-51).  Row 0 is the
+ * top row; texels are tightly packed u8. */
+typedef struct pt_texture {
+    uint64_t offset;    /* byte offset into pt_scene_desc.texels */
+    uint32_t width;
+    uint32_t height;
+    uint32_t channels;  /* 1 or 3 */
+    uint32_t _pad;
+} pt_texture;
+
+/* internal/material.rs:11-26.  tex_* = index into textures or -1. */
+typedef struct pt_material {
+    float albedo[3];
+    float emissive[3];
+    float opacity;
+    float metalness;
+    float roughness;
+    float ior;
+    int32_t tex_albedo;     /* rgb  */
+    int32_t tex_emissive;   /* rgb  */
+    int32_t tex_opacity;    /* luma */
+    int32_t tex_metalness;  /* luma */
+    int32_t tex_roughness;  /* luma */
+    int32_t tex_normal;     /* rgb  */
+} pt_material;
+
+/* internal/model.rs:10-21.  Meshes own triangles [tri_first, tri_first+tri_count)
+ * of pt_scene_desc.triangles; spheres use center/radius. */
+typedef struct pt_model {
+    int32_t kind;       /* PT_MODEL_* */
+    int32_t material;   /* index into materials */
+    uint32_t tri_first;
+    uint32_t tri_count;
+    float center[3];
+    float radius;
+} pt_model;
+
+/* internal/light.rs:6-17.  vec = position (point) or direction (directional). */
+typedef struct pt_light {
+    int32_t kind;       /* PT_LIGHT_* */
+    float vec[3];
+    float color[3];
+    float size;         /* unused by the integrator (hard shadows) */
+} pt_light;
+
+/* internal/camera.rs:7-48.  transform[4*k + r] = column k, row r (ISF
+ * "transform"[k] is column k, cgmath Matrix4 layout). */
+typedef struct pt_camera {
+    float transform[16];
+    float fov;          /* radians */
+    float zfar;
+    float znear;
+} pt_camera;
+
+/* internal/mod.rs:26-32.  triangles: 24 f32 per triangle in ISF order
+ * (position3, normal3, tex_coords2) x 3 vertices; models reference
+ * contiguous ranges in model order, so the global triangle index is the
+ * reference's (model index, triangle index) order. */
+typedef struct pt_scene_desc {
+    uint32_t n_models;
+    uint32_t n_materials;
+    uint32_t n_textures;
+    uint32_t n_lights;
+    uint64_t n_triangles;
+    uint64_t n_texel_bytes;
+    const pt_model* models;
+    const pt_material* materials;
+    const pt_texture* textures;
+    const pt_light* lights;
+    const float* triangles;
+    const uint8_t* texels;
+    pt_camera camera;
+    float background[3];
+    uint32_t _pad;
+} pt_scene_desc;
+
+/* config/profile.rs:10-25 (defaults 1920x1080, bounces 4, samples 64,
+ * COOK_TORRANCE, FILMIC). */
+typedef struct pt_profile {
+    uint32_t width;
+    uint32_t height;
+    uint32_t samples;
+    uint32_t bounces;
+    int32_t brdf;
+    int32_t tonemap;
+} pt_profile;
+
+/* pt_opts.flags */
+enum {
+    PT_FLAG_TIMING = 1u << 0,   /* record HIP events around every kernel launch */
+    PT_FLAG_COUNTERS = 1u << 1, /* run the instrumented kernel variant (ray /
+                                   node / triangle counters; not for timing)  */
+};
+
+/* Which pixels this call renders.  The image is cut into tile_w x tile_h
+ * tiles numbered row-major; this call renders tiles k with
+ * k % shard_count == shard_rank.  Every pixel keeps its GLOBAL
+ * index i = x + y*W in the seed formula (renderer/mod.rs:110-112), so any
+ * sharding is bit-identical to the unsharded render.  Output buffers are
+ * PACKED in local order: tiles in ascending k, row-major inside a tile
+ * (clipped at the image border).  shard_count <= 1 means the whole image in
+ * plain row-major order. */
+typedef struct pt_opts {
+    uint32_t flags;
+    int32_t device;        /* HIP device ordinal; -1 = current */
+    uint32_t shard_rank;
+    uint32_t shard_count;
+    uint32_t tile_w;       /* 0 -> 32 */
+    uint32_t tile_h;       /* 0 -> 32 */
+    uint32_t sample_batch; /* samples per kernel launch; 0 = library default */
+    uint32_t _pad;
+    void (*progress)(uint32_t done_samples, uint32_t total_samples, void* user);
+    void* progress_user;
+} pt_opts;
+
+typedef struct pt_scene pt_scene;
+
+/* ------------------------------------------------------------------ */
+/* the hot path                                                        */
+/* ------------------------------------------------------------------ */
+
+/* Upload a scene: builds the KD-tree (replaces kdtree-ray),
+ * the sRGB->linear table, and copies everything to the device. */
+int pt_scene_create(const pt_scene_desc* desc, int device, pt_scene** out);
+void pt_scene_destroy(pt_scene* scene);
+
+/* Number of pixels pt_render writes for (profile, opts). */
+uint64_t pt_local_pixel_count(const pt_profile* profile, const pt_opts* opts);
+/* local packed index -> global pixel index i = x + y*W; out has
+ * pt_local_pixel_count entries.  Host helper (no GPU needed). */
+int pt_local_pixel_map(const pt_profile* profile, const pt_opts* opts, uint32_t* out);
+
+/* Renderer::render (renderer/mod.rs:76-169) for this call's pixels.
+ * rgb8:  n_local*3 bytes, tone-mapped + gamma + u8 (mod.rs:335-353)  [may be NULL]
+ * accum: n_local*3 f32, SUM of sample radiance before the division by
+ *        `samples` (the reference's `buffer`, mod.rs:81,130)          [may be NULL]
+ * Both are HOST pointers; the call blocks until the image is complete. */
+int pt_render(const pt_scene* scene, const pt_profile* profile, const pt_opts* opts,
+              uint8_t* rgb8, float* accum);
+
+/* Same, with DEVICE pointers (hipMalloc'd or torch CUDA tensors) and a
+ * hipStream_t passed as void*.  Asynchronous with respect to the host
+ * unless PT_FLAG_TIMING is set; the caller synchronises the stream. */
+int pt_render_device(const pt_scene* scene, const pt_profile* profile, const pt_opts* opts,
+                     void* d_rgb8, void* d_accum, void* hip_stream);
+
+/* Scatter packed per-rank framebuffers (as produced by an all-gather of
+ * equal-sized, zero-padded packed slices; slice r starts at r*slice_pixels)
+ * into a row-major W*H image.  elem_bytes = 3 (rgb8) or 12 (f32 rgb).
+ * Device pointers; hip_stream as above. */
+int pt_assemble_tiles(const pt_profile* profile, uint32_t shard_count, uint32_t tile_w,
+                      uint32_t tile_h, uint64_t slice_pixels, uint32_t elem_bytes,
+                      const void* d_gathered, void* d_image, void* hip_stream);
+
+/* ------------------------------------------------------------------ */
+/* measurement                                                         */
+/* ------------------------------------------------------------------ */
+
+typedef struct pt_timing {
+    uint32_t launches;        /* integrator kernel launches in the last render */
+    float integrate_ms;       /* sum of their HIP-event durations             */
+    float postprocess_ms;     /* tone-map kernel                               */
+    float total_ms;           /* first launch -> last kernel done              */
+} pt_timing;
+
+/* Exact work counters from the instrumented variant (PT_FLAG_COUNTERS);
+ * they feed the algorithmic-bytes formula of SURVEY §8-d. */
+typedef struct pt_counters {
+    uint64_t samples;         /* path samples started                  */
+    uint64_t segments;        /* closest-hit ray casts (R_seg)         */
+    uint64_t shadow_rays;     /* shadow ray casts (R_sh)               */
+    uint64_t nodes_visited;   /* KD nodes touched (V)                  */
+    uint64_t tris_tested;     /* primitive tests (T)                   */
+    uint64_t shaded_hits;     /* material fetches (H)                  */
+    uint64_t rng_draws;
+    uint64_t restarts;        /* alpha-walk continuation casts         */
+} pt_counters;
+
+int pt_get_timing(const pt_scene* scene, pt_timing* out);
+int pt_get_counters(const pt_scene* scene, pt_counters* out);
+
+/* Scene statistics after the KD build. */
+typedef struct pt_scene_info {
+    uint64_t n_prims;         /* triangles + spheres              */
+    uint64_t n_kd_nodes;
+    uint64_t n_kd_leaves;
+    uint64_t n_leaf_refs;     /* primitive references in leaves   */
+    uint32_t kd_depth;
+    uint32_t has_translucent; /* any opacity != 1 or opacity texture */
+    float kd_build_seconds;
+    float upload_seconds;
+    uint64_t device_bytes;
+} pt_scene_info;
+int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out);
+
+/* ------------------------------------------------------------------ */
+/* test hooks (parity tests call the device code piecewise)            */
+/* ------------------------------------------------------------------ */
+
+/* One record per ray: the reference's first entry of ray_cast()
+ * (renderer/utils.rs:11-21): prim = global primitive index in (model,
+ * triangle) order (spheres count as one primitive each, interleaved in
+ * model order), or -1 for a miss. */
+typedef struct pt_hit {
+    int32_t prim;
+    int32_t flags;   /* bit0 backface (det<0), bit1 sphere, bit2 sphere exit hit */
+    float dist;
+    float u;
+    float v;
+} pt_hit;
+
+/* rays: n x 6 f32 (origin3, direction3), HOST pointers. */
+int pt_trace_rays(const pt_scene* scene, const float* rays, uint64_t n, pt_hit* out);
+
+/* Up to max_hits hits per ray in the reference's sorted order (all hits,
+ * stable by (dist, primitive order)); counts[i] = number written. */
+int pt_trace_rays_all(const pt_scene* scene, const float* rays, uint64_t n, uint32_t max_hits,
+                      pt_hit* out, uint32_t* counts);
+
+/* Triangle::intersect (internal/triangle.rs:37-82) on the device for n
+ * independent (ray, triangle) pairs: rays n x 6, tris n x 9 (v0,v1,v2). */
+int pt_intersect_triangles(int device, const float* rays, const float* tris, uint64_t n,
+                           pt_hit* out);
+
+/* First n_words of StdRng::seed_from_u64(seed) (rand 0.8.5 = ChaCha12,
+ * PCG32 key expansion) generated ON THE DEVICE for each seed. */
+int pt_rng_words(int device, const uint64_t* seeds, uint64_t n_seeds, uint32_t n_words,
+                 uint32_t* out);
+
+/* Device libm restatements evaluated on the GPU (bit-exactness checks
+ * against glibc): fn 0 = powf(x, 1/2.2f), 1 = acosf, 2 = sinf, 3 = cosf. */
+int pt_eval_math(int device, int fn, const float* x, uint64_t n, float* out);
+
+const char* pt_last_error(void);
+const char* pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */

@@ -1,0 +1,95 @@
+/*
+ * pthost.h — host-side surface that "stays" either side of the hot path
+ * (libpthost.so; no HIP dependency): the ISF scene loader, profile.yml
+ * parser, PNG codec, the deterministic PS5 stand-in scene generator and the
+ * KD-tree builder.  The `path-tracer` CLI, the tests and bench.py use it to
+ * produce the flat pt_scene_desc that pt_scene_create() consumes.
+ *
+ * Reference counterparts:
+ *   pth_scene_load_isf   src/scene/mod.rs:16-22, src/scene/isf.rs:5-142,
+ *                        src/scene/internal/{mod,model,material,texture_bank}.rs
+ *   pth_profile_load     src/config/profile.rs:10-40, resolution.rs:3-16
+ *   pth_png_*            image crate: open().into_rgb8()/into_luma8(), RgbImage::save
+ *   pth_kd_build         kdtree-ray KDTree::build (internal/mod.rs:42, model.rs:96)
+ */
+#ifndef PTHOST_H
+#define PTHOST_H
+
+#include "ptgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* An owned scene: `desc` points into storage owned by the handle. */
+typedef struct pth_scene pth_scene;
+
+int pth_scene_load_isf(const char* path, pth_scene** out);
+void pth_scene_free(pth_scene* s);
+const pt_scene_desc* pth_scene_desc(const pth_scene* s);
+
+/* Deterministic synthetic stand-in for the (unpublished) PS5 scene
+ * (SURVEY §8-d): ground quad + two tessellated curved shells + an emissive
+ * strip + one point light, black background, fov 0.6911112.
+ *   target_tris  approximate triangle count (500000 for BASELINE cfg 3/4)
+ *   seed         PCG32 seed for the vertex jitter (0 for the BASELINE configs)
+ *   flags        bit0: shells get opacity.factor 0.5 + a 1024^2 checker
+ *                opacity texture (BASELINE cfg 5) */
+int pth_scene_generate_ps5(uint64_t target_tris, uint64_t seed, uint32_t flags, pth_scene** out);
+
+/* Write a scene as ISF JSON (+ textures as PNG next to it). */
+int pth_scene_save_isf(const pth_scene* s, const char* dir);
+
+/* profile.yml: every key optional; unknown keys ignored. path == NULL gives
+ * Profile::default(). */
+int pth_profile_load(const char* path, pt_profile* out);
+int pth_profile_parse(const char* yaml_text, pt_profile* out);
+
+/* PNG. Decoded images are 8-bit; want_channels 1 (into_luma8) or 3
+ * (into_rgb8). *pixels is malloc'd; free with pth_free. */
+int pth_png_read(const char* path, uint32_t want_channels, uint32_t* w, uint32_t* h,
+                 uint8_t** pixels);
+int pth_png_decode(const uint8_t* data, size_t len, uint32_t want_channels, uint32_t* w,
+                   uint32_t* h, uint8_t** pixels);
+int pth_png_write_rgb8(const char* path, uint32_t w, uint32_t h, const uint8_t* rgb);
+void pth_free(void* p);
+
+/* ------------------------------------------------------------------ */
+/* KD-tree (single tree over every primitive of every model)           */
+/* ------------------------------------------------------------------ */
+
+/* 8-byte node (layout after pbrt's KdAccelNode):
+ *   interior: w0 = split position (f32 bits), w1 = (above_child << 2) | axis,
+ *             the below child is the next node
+ *   leaf:     w0 = first leaf-reference index,  w1 = (n_refs << 2) | 3 */
+typedef struct pth_kd_node {
+    uint32_t w0;
+    uint32_t w1;
+} pth_kd_node;
+
+typedef struct pth_kdtree {
+    uint64_t n_nodes;
+    uint64_t n_refs;
+    uint64_t n_leaves;
+    uint32_t depth;
+    uint32_t _pad;
+    float bounds_min[3];
+    float bounds_max[3];
+    pth_kd_node* nodes;     /* malloc'd */
+    uint32_t* refs;         /* malloc'd: primitive ids, leaf after leaf */
+    double build_seconds;
+} pth_kdtree;
+
+/* Primitive ids: one id per triangle and per sphere, in model order (a
+ * sphere takes one id at its model's position) — the reference's tie order
+ * for equal distances. */
+uint64_t pth_prim_count(const pt_scene_desc* desc);
+int pth_kd_build(const pt_scene_desc* desc, pth_kdtree* out);
+void pth_kd_free(pth_kdtree* kd);
+
+const char* pth_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTHOST_H */

@@ -1,0 +1,1046 @@
+// pt_oracle.cpp — CPU restatement of the reference's sampling hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Imported solely by tests/, smoke() and
+// bench.py's cpu_baseline leg; the product (libptgpu.so) never links or
+// calls this file.
+//
+// Every function cites the reference lines it follows
+// (/root/reference/src/...).  All arithmetic is scalar f32 in the
+// reference's operation order; build with -O2 -ffp-contract=off (no FMA
+// contraction, no fast-math) or the golden hashes break.
+// Third-party conventions (cgmath 0.18 op order, rand 0.8.5 StdRng =
+// ChaCha12 seeded through PCG32, LLVM powi expansion, saturating `as`
+// casts) are restated from their published definitions and
+// pinned end-to-end by the six golden hashes.
+#include "pt_oracle.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int set_err(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+// ------------------------------------------------------------------ cgmath
+// cgmath 0.18 Vector3<f32>: component-wise operators, dot = (x*x + y*y) + z*z,
+// magnitude = sqrt(dot), normalize = v * (1/|v|)  (SURVEY §8-a0).
+struct V3 {
+    float x, y, z;
+};
+inline V3 v3(float x, float y, float z) { return {x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline V3 mul_ew(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 div_ew(V3 a, V3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+inline float magnitude2(V3 a) { return dot(a, a); }
+inline float magnitude(V3 a) { return sqrtf(dot(a, a)); }
+inline V3 normalize(V3 a) { return a * (1.0f / magnitude(a)); }
+inline float sum(V3 a) { return a.x + a.y + a.z; }
+
+struct V2 {
+    float x, y;
+};
+inline V2 operator+(V2 a, V2 b) { return {a.x + b.x, a.y + b.y}; }
+inline V2 operator-(V2 a, V2 b) { return {a.x - b.x, a.y - b.y}; }
+inline V2 operator*(float s, V2 a) { return {s * a.x, s * a.y}; }
+
+// Rust scalar semantics
+inline float fmax_rs(float a, float b) { return fmaxf(a, b); }  // f32::max ignores NaN
+inline float powi5(float t) { return t * ((t * t) * (t * t)); }  // LLVM powi(x,5) expansion
+inline float powi2(float t) { return t * t; }
+inline uint8_t as_u8(float v) {  // `as u8`: saturating, NaN -> 0
+    if (!(v == v)) return 0;
+    if (v <= 0.f) return 0;
+    if (v >= 255.f) return 255;
+    return (uint8_t)v;
+}
+inline int64_t as_i64(float v) {  // `as i64`: truncating, saturating, NaN -> 0
+    if (!(v == v)) return 0;
+    if (v >= 9223372036854775807.0f) return INT64_MAX;
+    if (v <= -9223372036854775808.0f) return INT64_MIN;
+    return (int64_t)v;
+}
+inline int64_t rem_euclid(int64_t a, int64_t b) {
+    int64_t r = a % b;
+    return r < 0 ? r + (b < 0 ? -b : b) : r;
+}
+
+const float PI = 3.14159265358979323846f;  // std::f32::consts::PI
+
+// ------------------------------------------------------------------ rand
+// StdRng::seed_from_u64 (rand_core 0.6: PCG32 fills the 32-byte seed) and
+// ChaCha12 block function (rand_chacha 0.3); call sites renderer/mod.rs:110-112.
+struct StdRng {
+    uint32_t key[8];
+    uint64_t counter;
+    uint32_t buf[16];
+    int index;
+    uint64_t draws;
+
+    explicit StdRng(uint64_t state) {
+        const uint64_t MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+        for (int i = 0; i < 8; ++i) {
+            state = state * MUL + INC;
+            uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+            uint32_t rot = (uint32_t)(state >> 59);
+            key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        }
+        counter = 0;
+        index = 16;
+        draws = 0;
+    }
+    static inline uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+    void refill() {
+        uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                          key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                          (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+        uint32_t x[16];
+        memcpy(x, s, sizeof x);
+#define QR(a, b, c, d)                                                  \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 16);                  \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 12);                  \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 8);                   \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 7);
+        for (int r = 0; r < 6; ++r) {  // 12 rounds = 6 double rounds
+            QR(0, 4, 8, 12) QR(1, 5, 9, 13) QR(2, 6, 10, 14) QR(3, 7, 11, 15)
+            QR(0, 5, 10, 15) QR(1, 6, 11, 12) QR(2, 7, 8, 13) QR(3, 4, 9, 14)
+        }
+#undef QR
+        for (int i = 0; i < 16; ++i) buf[i] = x[i] + s[i];
+        ++counter;
+        index = 0;
+    }
+    uint32_t next_u32() {
+        if (index >= 16) refill();
+        return buf[index++];
+    }
+    // Standard distribution for f32: 24 random bits scaled by 2^-24.
+    float gen_f32() {
+        ++draws;
+        return (float)(next_u32() >> 8) * (1.0f / 16777216.0f);
+    }
+};
+
+// ------------------------------------------------------------------ scene
+struct Vertex {  // internal/vertex.rs:9-16
+    V3 position, normal;
+    V2 tex_coords;
+};
+struct Triangle {  // internal/triangle.rs:11
+    Vertex v[3];
+};
+
+struct Ray {  // renderer/ray.rs:4-10
+    V3 origin, direction;
+};
+
+struct Hit {  // renderer/hit.rs:5-37 (+ bookkeeping: model, primitive id)
+    bool sphere;
+    float dist;
+    V3 position;
+    V3 normal;
+    V3 tangent;
+    V2 tex_coords;
+    bool is_backface;
+    float u, v;      // barycentrics (test hook only)
+    int32_t model;
+    int32_t prim;
+    int32_t flags;
+};
+
+struct MaterialSample {  // renderer/material_sample.rs:6-18
+    float metalness, roughness;
+    V3 albedo;
+    float opacity;
+    V3 emissive;
+    float ior;
+};
+
+struct Box {
+    float mn[3], mx[3];
+};
+struct BvhNode {
+    Box box;
+    uint32_t left, right;  // children, or leaf: first/count with leaf flag
+    bool leaf;
+};
+
+}  // namespace
+
+struct pto_scene {
+    pt_scene_desc d;  // pointers re-targeted at the copies below
+    std::vector<pt_model> models;
+    std::vector<pt_material> materials;
+    std::vector<pt_texture> textures;
+    std::vector<pt_light> lights;
+    std::vector<float> triangles;
+    std::vector<uint8_t> texels;
+    std::vector<uint32_t> prim_first;  // per model: first global primitive id
+    std::vector<uint32_t> prim_model;  // per primitive: model index
+    int mode;
+    std::vector<BvhNode> bvh;
+    std::vector<uint32_t> bvh_prims;
+};
+
+namespace {
+
+inline Triangle load_triangle(const pto_scene& s, uint32_t tri) {
+    const float* f = &s.triangles[(size_t)tri * 24];
+    Triangle t;
+    for (int k = 0; k < 3; ++k) {
+        t.v[k].position = v3(f[8 * k], f[8 * k + 1], f[8 * k + 2]);
+        t.v[k].normal = v3(f[8 * k + 3], f[8 * k + 4], f[8 * k + 5]);
+        t.v[k].tex_coords = {f[8 * k + 6], f[8 * k + 7]};
+    }
+    return t;
+}
+
+// Hit::new_triangle — renderer/hit.rs:100-137
+Hit new_triangle(const Triangle& tr, float dist, V3 position, float u, float v, bool backface) {
+    Hit h{};
+    h.sphere = false;
+    h.dist = dist;
+    h.position = position;
+    h.is_backface = backface;
+    h.u = u;
+    h.v = v;
+    h.normal = (1.f - u - v) * tr.v[0].normal + u * tr.v[1].normal + v * tr.v[2].normal;
+    h.tex_coords = tr.v[0].tex_coords + u * (tr.v[1].tex_coords - tr.v[0].tex_coords) +
+                   v * (tr.v[2].tex_coords - tr.v[0].tex_coords);
+    V3 edge1 = tr.v[1].position - tr.v[0].position;
+    V3 edge2 = tr.v[2].position - tr.v[0].position;
+    V2 duv1 = tr.v[1].tex_coords - tr.v[0].tex_coords;
+    V2 duv2 = tr.v[2].tex_coords - tr.v[0].tex_coords;
+    float f = 1.f / (duv1.x * duv2.y - duv2.x * duv1.y);
+    h.tangent = normalize(v3(f * (duv2.y * edge1.x - duv1.y * edge2.x),
+                             f * (duv2.y * edge1.y - duv1.y * edge2.y),
+                             f * (duv2.y * edge1.z - duv1.y * edge2.z)));
+    return h;
+}
+
+// Triangle::intersect (Möller–Trumbore, no culling) — internal/triangle.rs:37-82
+bool intersect_triangle(const Triangle& tr, const Ray& ray, Hit* out) {
+    V3 v0v1 = tr.v[1].position - tr.v[0].position;
+    V3 v0v2 = tr.v[2].position - tr.v[0].position;
+    V3 pvec = cross(ray.direction, v0v2);
+    float det = dot(v0v1, pvec);
+    if (fabsf(det) < 0.000001f) return false;
+    float invdet = 1.f / det;
+    V3 tvec = ray.origin - tr.v[0].position;
+    float u = dot(tvec, pvec) * invdet;
+    if (!(u >= 0.0f && u <= 1.f)) return false;  // !(0.0..=1.).contains(&u)
+    V3 qvec = cross(tvec, v0v1);
+    float v = dot(ray.direction, qvec) * invdet;
+    if (v < 0.f || u + v > 1.f) return false;
+    float dist = dot(v0v2, qvec) * invdet;
+    if (dist < 0.000001f) return false;
+    *out = new_triangle(tr, dist, ray.origin + ray.direction * dist, u, v, det < 0.0f);
+    return true;
+}
+
+// Model::intersect, sphere arm — internal/model.rs:26-64.  Returns 0, 1 or 2
+// hits in the reference's order (entry hit first).
+int intersect_sphere(const pt_model& m, const Ray& ray, Hit out[2], uint64_t* numeric_errors) {
+    V3 center = v3(m.center[0], m.center[1], m.center[2]);
+    float radius = m.radius;
+    V3 ray_to_center = ray.origin - center;
+    float a = dot(ray.direction, ray.direction);
+    float b = 2.0f * dot(ray_to_center, ray.direction);
+    float c = dot(ray_to_center, ray_to_center) - radius * radius;
+    float discriminant = b * b - 4.0f * a * c;
+    if (discriminant < 0.0f) return 0;
+    float t1 = (-b - sqrtf(discriminant)) / (2.0f * a);
+    float t2 = (-b + sqrtf(discriminant)) / (2.0f * a);
+    if (!(t1 <= t2)) {  // assert!(t1 <= t2) panics in the reference
+        ++*numeric_errors;
+        return 0;
+    }
+    if (t2 < 0.0f) return 0;
+    V3 hit_point = ray.origin + ray.direction * t2;
+    Hit h2{};
+    h2.sphere = true;
+    h2.normal = -normalize(hit_point - center);
+    h2.dist = magnitude(hit_point - ray.origin);
+    h2.position = hit_point;
+    h2.flags = 2 | 4;
+    if (t1 < 0.0f) {
+        out[0] = h2;
+        return 1;
+    }
+    V3 hp1 = ray.origin + ray.direction * t1;
+    Hit h1{};
+    h1.sphere = true;
+    h1.normal = normalize(hp1 - center);
+    h1.dist = magnitude(hp1 - ray.origin);
+    h1.position = hp1;
+    h1.flags = 2;
+    out[0] = h1;
+    out[1] = h2;
+    return 2;
+}
+
+// ------------------------------------------------------------------ candidate filter
+// Stand-in for kdtree-ray's KDTree::intersect (candidate primitives whose
+// bounding volumes the ray may touch).  Median-split AABB tree with padded
+// boxes and a conservative slab test; result-neutral by construction because
+// every candidate still goes through intersect_triangle / intersect_sphere.
+void prim_box(const pto_scene& s, uint32_t prim, Box& b) {
+    uint32_t m = s.prim_model[prim];
+    const pt_model& mo = s.models[m];
+    if (mo.kind == PT_MODEL_MESH) {
+        const float* f = &s.triangles[(size_t)(mo.tri_first + (prim - s.prim_first[m])) * 24];
+        for (int a = 0; a < 3; ++a) {
+            b.mn[a] = std::min(std::min(f[a], f[8 + a]), f[16 + a]);
+            b.mx[a] = std::max(std::max(f[a], f[8 + a]), f[16 + a]);
+        }
+    } else {
+        for (int a = 0; a < 3; ++a) {
+            b.mn[a] = mo.center[a] - mo.radius;
+            b.mx[a] = mo.center[a] + mo.radius;
+        }
+    }
+    for (int a = 0; a < 3; ++a) {  // conservative padding
+        float pad = 1e-4f * std::max(fabsf(b.mn[a]), fabsf(b.mx[a])) + 1e-5f;
+        b.mn[a] -= pad;
+        b.mx[a] += pad;
+    }
+}
+
+uint32_t bvh_build(pto_scene& s, std::vector<Box>& boxes, std::vector<V3>& cent, uint32_t first,
+                   uint32_t count) {
+    BvhNode node{};
+    for (int a = 0; a < 3; ++a) {
+        node.box.mn[a] = INFINITY;
+        node.box.mx[a] = -INFINITY;
+    }
+    float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = first; i < first + count; ++i) {
+        const Box& b = boxes[s.bvh_prims[i]];
+        const V3& c = cent[s.bvh_prims[i]];
+        const float cc[3] = {c.x, c.y, c.z};
+        for (int a = 0; a < 3; ++a) {
+            node.box.mn[a] = std::min(node.box.mn[a], b.mn[a]);
+            node.box.mx[a] = std::max(node.box.mx[a], b.mx[a]);
+            cmn[a] = std::min(cmn[a], cc[a]);
+            cmx[a] = std::max(cmx[a], cc[a]);
+        }
+    }
+    uint32_t idx = (uint32_t)s.bvh.size();
+    s.bvh.push_back(node);
+    int axis = 0;
+    if (cmx[1] - cmn[1] > cmx[axis] - cmn[axis]) axis = 1;
+    if (cmx[2] - cmn[2] > cmx[axis] - cmn[axis]) axis = 2;
+    if (count <= 4 || !(cmx[axis] > cmn[axis])) {
+        s.bvh[idx].leaf = true;
+        s.bvh[idx].left = first;
+        s.bvh[idx].right = count;
+        return idx;
+    }
+    uint32_t mid = first + count / 2;
+    auto key = [&](uint32_t p) { return axis == 0 ? cent[p].x : (axis == 1 ? cent[p].y : cent[p].z); };
+    std::nth_element(s.bvh_prims.begin() + first, s.bvh_prims.begin() + mid,
+                     s.bvh_prims.begin() + first + count,
+                     [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+    uint32_t l = bvh_build(s, boxes, cent, first, mid - first);
+    uint32_t r = bvh_build(s, boxes, cent, mid, first + count - mid);
+    s.bvh[idx].leaf = false;
+    s.bvh[idx].left = l;
+    s.bvh[idx].right = r;
+    return idx;
+}
+
+inline bool ray_box(const Box& b, const Ray& r, const float inv[3]) {
+    const float o[3] = {r.origin.x, r.origin.y, r.origin.z};
+    const float d[3] = {r.direction.x, r.direction.y, r.direction.z};
+    float t0 = 0.f, t1 = INFINITY;
+    for (int a = 0; a < 3; ++a) {
+        if (d[a] == 0.f || !(d[a] == d[a])) {
+            if (o[a] < b.mn[a] || o[a] > b.mx[a]) return false;
+            continue;
+        }
+        float ta = (b.mn[a] - o[a]) * inv[a], tb = (b.mx[a] - o[a]) * inv[a];
+        if (ta > tb) std::swap(ta, tb);
+        tb *= 1.00001f;  // conservative (never reject a box the ray touches)
+        ta *= ta > 0 ? 0.99999f : 1.00001f;
+        if (ta > t0) t0 = ta;
+        if (tb < t1) t1 = tb;
+        if (t0 > t1) return false;
+    }
+    return true;
+}
+
+void candidates(const pto_scene& s, const Ray& ray, std::vector<uint32_t>& out) {
+    out.clear();
+    if (s.bvh.empty()) return;
+    float inv[3] = {1.f / ray.direction.x, 1.f / ray.direction.y, 1.f / ray.direction.z};
+    uint32_t stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const BvhNode& n = s.bvh[stack[--sp]];
+        if (!ray_box(n.box, ray, inv)) continue;
+        if (n.leaf) {
+            for (uint32_t i = 0; i < n.right; ++i) out.push_back(s.bvh_prims[n.left + i]);
+        } else {
+            stack[sp++] = n.left;
+            stack[sp++] = n.right;
+        }
+    }
+    // ascending primitive id = (model index, triangle index): the reference's
+    // order for equal distances
+    std::sort(out.begin(), out.end());
+}
+
+// ------------------------------------------------------------------ ray_cast
+struct CastScratch {
+    std::vector<Hit> hits;
+    std::vector<uint32_t> cand;
+};
+
+void test_prim(const pto_scene& s, uint32_t prim, const Ray& ray, std::vector<Hit>& hits,
+               uint64_t* numeric_errors) {
+    uint32_t m = s.prim_model[prim];
+    const pt_model& mo = s.models[m];
+    if (mo.kind == PT_MODEL_MESH) {
+        Triangle tr = load_triangle(s, mo.tri_first + (prim - s.prim_first[m]));
+        Hit h;
+        if (intersect_triangle(tr, ray, &h)) {
+            h.model = (int32_t)m;
+            h.prim = (int32_t)prim;
+            h.flags = h.is_backface ? 1 : 0;
+            hits.push_back(h);
+        }
+    } else {
+        Hit hs[2];
+        int n = intersect_sphere(mo, ray, hs, numeric_errors);
+        for (int i = 0; i < n; ++i) {
+            hs[i].model = (int32_t)m;
+            hs[i].prim = (int32_t)prim;
+            hits.push_back(hs[i]);
+        }
+    }
+}
+
+// ray_cast — renderer/utils.rs:11-21: every hit of every model, stable-sorted by distance.
+void ray_cast(const pto_scene& s, const Ray& ray, CastScratch& sc, uint64_t* numeric_errors) {
+    sc.hits.clear();
+    if (s.mode == PTO_BRUTE_FORCE) {
+        uint32_t n = (uint32_t)s.prim_model.size();
+        for (uint32_t p = 0; p < n; ++p) test_prim(s, p, ray, sc.hits, numeric_errors);
+    } else {
+        candidates(s, ray, sc.cand);
+        for (uint32_t p : sc.cand) test_prim(s, p, ray, sc.hits, numeric_errors);
+    }
+    // partial_cmp().unwrap() panics on NaN (utils.rs:19): count it, drop the hit
+    size_t w = 0;
+    for (size_t i = 0; i < sc.hits.size(); ++i) {
+        if (sc.hits[i].dist == sc.hits[i].dist) sc.hits[w++] = sc.hits[i];
+        else ++*numeric_errors;
+    }
+    sc.hits.resize(w);
+    std::stable_sort(sc.hits.begin(), sc.hits.end(),
+                     [](const Hit& a, const Hit& b) { return a.dist < b.dist; });
+}
+
+// ------------------------------------------------------------------ materials
+// Material::get_pixel — internal/material.rs:115-130 (nearest texel, wrap, row 0 = top)
+inline const uint8_t* get_pixel(const pto_scene& s, int32_t tex, V2 uv) {
+    const pt_texture& t = s.textures[tex];
+    float cx = uv.x * (float)t.width, cy = uv.y * (float)t.height;
+    int64_t px = rem_euclid(as_i64(cx), (int64_t)t.width);
+    int64_t py = rem_euclid(as_i64(cy), (int64_t)t.height);
+    return &s.texels[t.offset + ((size_t)py * t.width + (size_t)px) * t.channels];
+}
+
+// Material::get_* — internal/material.rs:132-214
+V3 get_albedo(const pto_scene& s, const pt_material& m, V2 uv) {
+    V3 factor = v3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    if (m.tex_albedo >= 0) {
+        const uint8_t* p = get_pixel(s, m.tex_albedo, uv);
+        return mul_ew(v3(powf((float)p[0] / 255.0f, 2.2f), powf((float)p[1] / 255.0f, 2.2f),
+                         powf((float)p[2] / 255.0f, 2.2f)),
+                      factor);
+    }
+    return factor;
+}
+float get_luma(const pto_scene& s, int32_t tex, float factor, V2 uv) {
+    if (tex >= 0) return (float)get_pixel(s, tex, uv)[0] / 255.f * factor;
+    return factor;
+}
+V3 get_emissive(const pto_scene& s, const pt_material& m, V2 uv) {
+    V3 factor = v3(m.emissive[0], m.emissive[1], m.emissive[2]);
+    if (m.tex_emissive >= 0) {
+        const uint8_t* p = get_pixel(s, m.tex_emissive, uv);
+        return mul_ew(v3((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f), factor);
+    }
+    return factor;
+}
+
+// MaterialSample::new / simple — renderer/material_sample.rs:20-40
+MaterialSample material_sample_new(const pto_scene& s, const pt_material& m, V2 uv) {
+    MaterialSample r;
+    r.metalness = get_luma(s, m.tex_metalness, m.metalness, uv);
+    r.roughness = fmax_rs(get_luma(s, m.tex_roughness, m.roughness, uv), 0.0001f);
+    r.albedo = get_albedo(s, m, uv);
+    r.opacity = get_luma(s, m.tex_opacity, m.opacity, uv);
+    r.emissive = get_emissive(s, m, uv);
+    r.ior = m.ior;
+    return r;
+}
+MaterialSample material_sample_simple(const pt_material& m) {
+    MaterialSample r;
+    r.metalness = m.metalness;
+    r.roughness = fmax_rs(m.roughness, 0.0001f);
+    r.albedo = v3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    r.opacity = m.opacity;
+    r.emissive = v3(m.emissive[0], m.emissive[1], m.emissive[2]);
+    r.ior = m.ior;
+    return r;
+}
+
+// Hit::get_material_sample — renderer/hit.rs:84-91.  NOTE: `hit` supplies the
+// kind and tex_coords, `model` the material; get_light_info's point-light arm
+// passes the SHADED hit with the OCCLUDER's model (mod.rs:324).
+MaterialSample get_material_sample(const pto_scene& s, const Hit& hit, int32_t model) {
+    const pt_material& m = s.materials[s.models[model].material];
+    if (hit.sphere) return material_sample_simple(m);
+    return material_sample_new(s, m, hit.tex_coords);
+}
+
+// Hit::get_normal — renderer/hit.rs:55-82
+V3 get_normal(const pto_scene& s, const Hit& hit, int32_t model) {
+    if (hit.sphere) return hit.normal;
+    const pt_material& m = s.materials[s.models[model].material];
+    V3 normal;
+    if (m.tex_normal >= 0) {  // Material::get_normal — internal/material.rs:178-187
+        const uint8_t* p = get_pixel(s, m.tex_normal, hit.tex_coords);
+        V3 nm = v3((float)p[0] / 127.5f - 1.f, (float)p[1] / 127.5f - 1.f, (float)p[2] / 127.5f - 1.f);
+        V3 bitangent = cross(hit.normal, hit.tangent);
+        // Matrix3::from_cols(tangent, bitangent, normal) * nm
+        V3 r = hit.tangent * nm.x + bitangent * nm.y + hit.normal * nm.z;
+        normal = normalize(r);
+    } else {
+        normal = hit.normal;
+    }
+    return hit.is_backface ? -normal : normal;
+}
+
+// ------------------------------------------------------------------ Cook–Torrance
+// renderer/brdf/cook_torrance.rs:10-183, renderer/brdf/mod.rs:35-48, renderer/utils.rs:34-36
+struct CookTorrance {
+    float metalness, roughness;
+    V3 albedo, emissive, f0, microfacet_normal;
+
+    explicit CookTorrance(const MaterialSample& m) {  // :95-104
+        metalness = m.metalness;
+        roughness = m.roughness;
+        albedo = m.albedo;
+        emissive = m.emissive;
+        f0 = v3(0.04f, 0.04f, 0.04f) * (1.f - m.metalness) + m.albedo * m.metalness;  // :180-182
+        microfacet_normal = v3(0, 0, 0);
+    }
+    V3 fresnel_schlick(float cos_theta) const {  // :143-147
+        return f0 + v3(1.f - f0.x, 1.f - f0.y, 1.f - f0.z) * powi5(1.f - cos_theta);
+    }
+    static float geometry_schlick_ggx(float n_dot_v, float k) {  // :149-154
+        float num = n_dot_v;
+        float denom = n_dot_v * (1.f - k) + k;
+        return num / denom;
+    }
+    float geometry_smith(V3 n, V3 v, V3 l) const {  // :156-165
+        float a = roughness;
+        float n_dot_v = fmax_rs(dot(n, v), 0.f);
+        float n_dot_l = fmax_rs(dot(n, l), 0.f);
+        float k = powi2(a + 1.f) / 8.f;
+        return geometry_schlick_ggx(n_dot_v, k) * geometry_schlick_ggx(n_dot_l, k);
+    }
+    float distribution_ggx(V3 n, V3 h) const {  // :167-178
+        float a = roughness * roughness;
+        float a2 = a * a;
+        float n_dot_h = fmax_rs(dot(n, h), 0.f);
+        float n_dot_h_2 = n_dot_h * n_dot_h;
+        float num = a2;
+        float denom = n_dot_h_2 * (a2 - 1.f) + 1.f;
+        denom = PI * denom * denom;
+        return num / denom;
+    }
+    V3 compute_diffuse(V3 ks, V3 n, V3 l) const {  // :107-117
+        V3 kd = v3(1.f - ks.x, 1.f - ks.y, 1.f - ks.z) * (1.f - metalness);
+        V3 diffuse = mul_ew(kd, albedo) / PI;
+        float cosine_term = fmax_rs(dot(n, l), 0.f);
+        return diffuse * cosine_term;
+    }
+    V3 eval_direct(V3 n, V3 view, V3 light) const {  // :34-58
+        V3 halfway = normalize(view + light);
+        float d = distribution_ggx(n, halfway);
+        V3 f = fresnel_schlick(fmax_rs(dot(halfway, view), 0.f));
+        float g = geometry_smith(n, view, light);
+        V3 specular = (d * f * g) / fmax_rs(4.f * fmax_rs(dot(n, view), 0.f) * fmax_rs(dot(n, light), 0.f), 0.0001f);
+        float cosine_term = fmax_rs(dot(n, light), 0.f);
+        specular = specular * cosine_term;
+        V3 diffuse = compute_diffuse(f, n, light);
+        return diffuse + specular + emissive;
+    }
+    V3 eval_indirect(V3 n, V3 view, V3 light) const {  // :60-86
+        V3 halfway = normalize(view + light);
+        V3 f = fresnel_schlick(fmax_rs(dot(halfway, view), 0.f));
+        float g = geometry_smith(n, view, light);
+        V3 specular;
+        if (dot(n, light) > 0.f) {
+            float weight_num = fabsf(dot(view, microfacet_normal));
+            float weight_denom = fabsf(dot(view, n)) * fabsf(dot(microfacet_normal, n));
+            float weight = weight_num / weight_denom;
+            specular = f * g * weight;
+        } else {
+            specular = v3(0, 0, 0);
+        }
+        V3 diffuse = compute_diffuse(f, n, light);
+        return diffuse + specular;
+    }
+    // transform_to_world — renderer/brdf/mod.rs:35-48
+    static V3 transform_to_world(V3 vec, V3 n) {
+        V3 nt;
+        if (fabsf(n.x) > fabsf(n.y)) nt = v3(n.z, 0.f, -n.x) / sqrtf(n.x * n.x + n.z * n.z);
+        else nt = v3(0.f, -n.z, n.y) / sqrtf(n.y * n.y + n.z * n.z);
+        V3 nb = cross(n, nt);
+        return v3(vec.x * nb.x + vec.y * n.x + vec.z * nt.x, vec.x * nb.y + vec.y * n.y + vec.z * nt.y,
+                  vec.x * nb.z + vec.y * n.z + vec.z * nt.z);
+    }
+    void compute_microfacet_normal(V3 n, StdRng& rng) {  // :119-141
+        float a = roughness * roughness;
+        float a2 = a * a;
+        float r1 = rng.gen_f32();
+        float r2 = rng.gen_f32();
+        float theta = acosf(sqrtf((1.f - r1) / (r1 * (a2 - 1.f) + 1.f)));
+        float phi = 2.f * PI * r2;
+        float sin_theta = sinf(theta);
+        float x = sin_theta * cosf(phi);
+        float y = cosf(theta);
+        float z = sin_theta * sinf(phi);
+        V3 m = normalize(v3(x, y, z));
+        microfacet_normal = normalize(transform_to_world(m, n));
+    }
+    V3 sample(V3 n, V3 v, StdRng& rng) {  // :20-32
+        compute_microfacet_normal(n, rng);
+        // reflection(i, n) = 2 * max(i.n, 0) * n - i  (renderer/utils.rs:34-36)
+        V3 sample_dir = (2.f * fmax_rs(dot(v, microfacet_normal), 0.f)) * microfacet_normal - v;
+        return normalize(sample_dir);
+    }
+    static float pdf() { return 1.f; }  // :88-91
+};
+
+// ------------------------------------------------------------------ integrator
+struct SurfaceInfo {  // renderer/mod.rs:50-54
+    Hit hit;
+    int32_t model;
+    MaterialSample material;
+    V3 normal;
+};
+struct RadianceInfo {  // renderer/mod.rs:41-48
+    V3 color, throughput;
+};
+
+const float NORMAL_BIAS = 0.00001f;  // renderer/mod.rs:58
+
+struct Ctx {
+    const pto_scene& s;
+    const pt_profile& profile;
+    CastScratch primary, shadow;
+    pto_stats st{};
+    Ctx(const pto_scene& sc, const pt_profile& p) : s(sc), profile(p) {}
+};
+
+// Renderer::get_light_info — renderer/mod.rs:281-333
+void get_light_info(Ctx& c, const pt_light& light, const Hit& hit, V3* radiance, V3* direction_out) {
+    V3 color = v3(light.color[0], light.color[1], light.color[2]);
+    if (light.kind == PT_LIGHT_DIRECTIONAL) {
+        V3 direction = v3(light.vec[0], light.vec[1], light.vec[2]);
+        Ray shadow_ray{hit.position + hit.normal * NORMAL_BIAS, -1.f * direction};
+        ++c.st.shadow_rays;
+        ray_cast(c.s, shadow_ray, c.shadow, &c.st.numeric_errors);
+        for (const Hit& sh : c.shadow.hits) {
+            MaterialSample ms = get_material_sample(c.s, sh, sh.model);
+            color = color * (1.f - ms.opacity);
+            if (sum(color) == 0.f) break;
+        }
+        *radiance = color;
+        *direction_out = direction;
+    } else {
+        V3 position = v3(light.vec[0], light.vec[1], light.vec[2]);
+        V3 direction = hit.position - position;
+        float dist = magnitude(direction);
+        direction = normalize(direction);
+        Ray shadow_ray{hit.position + hit.normal * NORMAL_BIAS, -1.f * direction};
+        float dissipation = 4.f * PI * dist * dist;
+        V3 light_dissipated = color / dissipation;
+        ++c.st.shadow_rays;
+        ray_cast(c.s, shadow_ray, c.shadow, &c.st.numeric_errors);
+        for (const Hit& sh : c.shadow.hits) {
+            if (magnitude(sh.position - hit.position) > dist) break;
+            // quirk kept: the SHADED hit's kind/uv with the occluder's material (mod.rs:324)
+            MaterialSample ms = get_material_sample(c.s, hit, sh.model);
+            light_dissipated = light_dissipated * (1.f - ms.opacity);
+            if (sum(light_dissipated) == 0.f) break;
+        }
+        *radiance = light_dissipated;
+        *direction_out = direction;
+    }
+}
+
+// Renderer::compute_radiance — renderer/mod.rs:230-278
+void compute_radiance(Ctx& c, RadianceInfo& rad, const SurfaceInfo& si, V3 view_direction,
+                      bool compute_indirect, StdRng& rng, Ray* ray_out) {
+    CookTorrance brdf(si.material);  // get_brdf: renderer/brdf/mod.rs:57-61
+    V3 color = rad.color;
+    V3 throughput = rad.throughput;
+    Ray ray{v3(0, 0, 0), v3(0, 0, 0)};
+
+    color = color + mul_ew(throughput, si.material.emissive);
+
+    for (uint32_t li = 0; li < c.s.d.n_lights; ++li) {
+        V3 light_radiance, light_direction;
+        get_light_info(c, c.s.lights[li], si.hit, &light_radiance, &light_direction);
+        if (light_radiance.x == 0.f && light_radiance.y == 0.f && light_radiance.z == 0.f) continue;
+        V3 reversed_light_dir = -1.f * light_direction;
+        color = color + mul_ew(mul_ew(throughput, brdf.eval_direct(si.normal, view_direction, reversed_light_dir)),
+                               light_radiance);
+    }
+
+    if (compute_indirect) {
+        ray.origin = si.hit.position + si.hit.normal * NORMAL_BIAS;
+        ray.direction = brdf.sample(si.normal, view_direction, rng);
+        V3 sample_radiance = brdf.eval_indirect(si.normal, view_direction, ray.direction);
+        V3 weighted = sample_radiance / CookTorrance::pdf();
+        throughput = mul_ew(throughput, weighted);
+    }
+    rad.color = color;
+    rad.throughput = throughput;
+    *ray_out = ray;
+}
+
+// russian_roulette — renderer/utils.rs:23-31
+bool russian_roulette(V3& throughput, StdRng& rng) {
+    float rr_proba = fmax_rs(fmax_rs(throughput.x, throughput.y), throughput.z);
+    throughput = throughput * (1.f / rr_proba);
+    return rng.gen_f32() > rr_proba;
+}
+
+// Renderer::render_pixel — renderer/mod.rs:172-228
+V3 render_pixel(Ctx& c, Ray ray, StdRng& rng) {
+    RadianceInfo rad{v3(0, 0, 0), v3(1, 1, 1)};
+    V3 background = v3(c.s.d.background[0], c.s.d.background[1], c.s.d.background[2]);
+    for (uint32_t bounce = 0; bounce < c.profile.bounces + 1; ++bounce) {
+        ++c.st.segments;
+        ray_cast(c.s, ray, c.primary, &c.st.numeric_errors);
+        if (c.primary.hits.empty()) return rad.color + mul_ew(rad.throughput, background);
+
+        SurfaceInfo si{};
+        for (const Hit& hit : c.primary.hits) {
+            MaterialSample ms = get_material_sample(c.s, hit, hit.model);
+            V3 normal = get_normal(c.s, hit, hit.model);
+            float opacity = ms.opacity;
+            ++c.st.shaded_hits;
+            si.hit = hit;
+            si.model = hit.model;
+            si.material = ms;
+            si.normal = normal;
+            if (opacity >= 1.f || (opacity > 0.001f && rng.gen_f32() < opacity)) break;
+        }
+
+        V3 view_direction = -1.f * ray.direction;
+        compute_radiance(c, rad, si, view_direction, bounce < c.profile.bounces, rng, &ray);
+
+        if (magnitude2(rad.throughput) < 0.00001f) return rad.color;
+        if (bounce > 3 && russian_roulette(rad.throughput, rng)) return rad.color;
+    }
+    return rad.color;
+}
+
+// tonemap — renderer/tonemap.rs:15-54
+V3 tonemap(int type, V3 color) {
+    switch (type) {
+        case PT_TONEMAP_REINHARD: return div_ew(color, color + v3(1.f, 1.f, 1.f));
+        case PT_TONEMAP_ACES: {
+            float a = 2.51f, cc = 2.43f;
+            V3 b = v3(0.03f, 0.03f, 0.03f), d = v3(0.59f, 0.59f, 0.59f), e = v3(0.14f, 0.14f, 0.14f);
+            V3 num = mul_ew(color, a * color + b);
+            V3 denom = mul_ew(color, cc * color + d) + e;
+            V3 res = div_ew(num, denom);
+            auto clamp01 = [](float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); };  // f32::clamp keeps NaN
+            return v3(clamp01(res.x), clamp01(res.y), clamp01(res.z));
+        }
+        default: {  // FILMIC
+            V3 a = v3(0.004f, 0.004f, 0.004f);
+            V3 col = color - a;
+            col = v3(fmax_rs(col.x, 0.f), fmax_rs(col.y, 0.f), fmax_rs(col.z, 0.f));
+            V3 b = v3(0.5f, 0.5f, 0.5f), cc = v3(1.7f, 1.7f, 1.7f), d = v3(0.06f, 0.06f, 0.06f);
+            V3 num = mul_ew(col, 6.2f * col + b);
+            V3 denom = mul_ew(col, 6.2f * col + cc) + d;
+            return div_ew(num, denom);
+        }
+    }
+}
+
+// Renderer::post_processing — renderer/mod.rs:335-353
+void post_processing(int tonemap_type, V3 color, uint8_t out[3]) {
+    color = tonemap(tonemap_type, color);
+    float gamma = 2.2f;
+    V3 g = v3(powf(color.x, 1.f / gamma), powf(color.y, 1.f / gamma), powf(color.z, 1.f / gamma));
+    out[0] = as_u8(g.x * 255.f);
+    out[1] = as_u8(g.y * 255.f);
+    out[2] = as_u8(g.z * 255.f);
+}
+
+// Camera ray of renderer/mod.rs:107-124; Camera::apply_transform_vector /
+// position — internal/camera.rs:36-48.
+Ray primary_ray(const pto_scene& s, const pt_profile& p, uint64_t i, StdRng& rng) {
+    uint32_t width = p.width, height = p.height;
+    uint32_t x = (uint32_t)i % width;
+    uint32_t y = (uint32_t)i / width;
+    float width_f = (float)width, height_f = (float)height;
+    float image_ratio = width_f / height_f;
+    float fov = s.d.camera.fov;
+
+    float screen_x = (float)x + rng.gen_f32();
+    screen_x = screen_x / width_f * 2.f - 1.f;
+    screen_x *= tanf(fov / 2.f) * image_ratio;
+
+    float screen_y = (float)y + rng.gen_f32();
+    screen_y = 1.f - screen_y / height_f * 2.f;
+    screen_y *= tanf(fov / 2.f);
+
+    V3 dir = normalize(v3(screen_x, screen_y, -1.f));
+    const float* M = s.d.camera.transform;  // column-major
+    V3 c0 = v3(M[0], M[1], M[2]), c1 = v3(M[4], M[5], M[6]), c2 = v3(M[8], M[9], M[10]),
+       c3 = v3(M[12], M[13], M[14]);
+    // Matrix4 * Vector4(x, y, z, 0): c0*x + c1*y + c2*z + c3*0
+    V3 world = c0 * dir.x + c1 * dir.y + c2 * dir.z + c3 * 0.0f;
+    return Ray{c3, world};
+}
+
+}  // namespace
+
+// ==================================================================== C API
+extern "C" {
+
+const char* pto_last_error(void) { return g_err.c_str(); }
+
+int pto_scene_create(const pt_scene_desc* desc, int mode, pto_scene** out) {
+    if (!desc || !out) return set_err(PT_ERR_INVALID, "pto_scene_create: null argument");
+    pto_scene* s = new pto_scene();
+    s->d = *desc;
+    s->mode = mode;
+    s->models.assign(desc->models, desc->models + desc->n_models);
+    s->materials.assign(desc->materials, desc->materials + desc->n_materials);
+    s->textures.assign(desc->textures, desc->textures + desc->n_textures);
+    s->lights.assign(desc->lights, desc->lights + desc->n_lights);
+    s->triangles.assign(desc->triangles, desc->triangles + desc->n_triangles * 24);
+    s->texels.assign(desc->texels, desc->texels + desc->n_texel_bytes);
+    s->d.models = s->models.data();
+    s->d.materials = s->materials.data();
+    s->d.textures = s->textures.data();
+    s->d.lights = s->lights.data();
+    s->d.triangles = s->triangles.data();
+    s->d.texels = s->texels.data();
+    for (uint32_t m = 0; m < desc->n_models; ++m) {
+        const pt_model& mo = s->models[m];
+        if (mo.material < 0 || (uint32_t)mo.material >= desc->n_materials) {
+            delete s;
+            return set_err(PT_ERR_INVALID, "model %u: material index out of range", m);
+        }
+        s->prim_first.push_back((uint32_t)s->prim_model.size());
+        uint32_t n = mo.kind == PT_MODEL_MESH ? mo.tri_count : 1;
+        for (uint32_t k = 0; k < n; ++k) s->prim_model.push_back(m);
+    }
+    if (mode == PTO_BVH && !s->prim_model.empty()) {
+        uint32_t n = (uint32_t)s->prim_model.size();
+        std::vector<Box> boxes(n);
+        std::vector<V3> cent(n);
+        s->bvh_prims.resize(n);
+        for (uint32_t p = 0; p < n; ++p) {
+            prim_box(*s, p, boxes[p]);
+            cent[p] = v3(0.5f * (boxes[p].mn[0] + boxes[p].mx[0]), 0.5f * (boxes[p].mn[1] + boxes[p].mx[1]),
+                         0.5f * (boxes[p].mn[2] + boxes[p].mx[2]));
+            s->bvh_prims[p] = p;
+        }
+        s->bvh.reserve(2 * n);
+        bvh_build(*s, boxes, cent, 0, n);
+    }
+    *out = s;
+    return PT_OK;
+}
+
+void pto_scene_destroy(pto_scene* s) { delete s; }
+
+int pto_render(const pto_scene* s, const pt_profile* profile, uint64_t pixel_begin, uint64_t pixel_end,
+               int threads, uint8_t* rgb8, float* accum, pto_stats* stats) {
+    if (!s || !profile) return set_err(PT_ERR_INVALID, "pto_render: null argument");
+    const pt_profile p = *profile;
+    uint64_t npix = (uint64_t)p.width * p.height;
+    if (pixel_end == 0) pixel_end = npix;
+    if (pixel_begin > pixel_end || pixel_end > npix) return set_err(PT_ERR_INVALID, "pto_render: bad pixel range");
+    if (p.samples == 0 || p.width == 0 || p.height == 0) return set_err(PT_ERR_INVALID, "pto_render: empty profile");
+    if (threads <= 0) threads = omp_get_max_threads();
+    pto_stats total{};
+#pragma omp parallel num_threads(threads)
+    {
+        Ctx c(*s, p);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t ii = (int64_t)pixel_begin; ii < (int64_t)pixel_end; ++ii) {
+            uint64_t i = (uint64_t)ii;
+            V3 pixel = v3(0, 0, 0);  // the reference's `buffer[i]` (mod.rs:81)
+            for (uint32_t current_sample = 1; current_sample < p.samples + 1; ++current_sample) {
+                StdRng rng((uint64_t)current_sample + i * (uint64_t)p.samples);  // mod.rs:110-112
+                Ray ray = primary_ray(*s, p, i, rng);
+                V3 color = render_pixel(c, ray, rng);
+                pixel = pixel + color;  // *pixel += color (mod.rs:130)
+                ++c.st.samples;
+                c.st.rng_draws += rng.draws;
+                if (rng.draws > c.st.max_draws_per_sample) c.st.max_draws_per_sample = rng.draws;
+            }
+            uint64_t o = i - pixel_begin;
+            if (accum) {
+                accum[3 * o] = pixel.x;
+                accum[3 * o + 1] = pixel.y;
+                accum[3 * o + 2] = pixel.z;
+            }
+            if (rgb8) post_processing(p.tonemap, pixel / (float)p.samples, rgb8 + 3 * o);  // mod.rs:150-162
+        }
+#pragma omp critical
+        {
+            total.samples += c.st.samples;
+            total.segments += c.st.segments;
+            total.shadow_rays += c.st.shadow_rays;
+            total.shaded_hits += c.st.shaded_hits;
+            total.rng_draws += c.st.rng_draws;
+            total.numeric_errors += c.st.numeric_errors;
+            total.max_draws_per_sample = std::max(total.max_draws_per_sample, c.st.max_draws_per_sample);
+        }
+    }
+    if (stats) *stats = total;
+    return PT_OK;
+}
+
+int pto_post_process(const pt_profile* profile, const float* accum, uint64_t n, uint8_t* rgb8) {
+    if (!profile || !accum || !rgb8) return set_err(PT_ERR_INVALID, "pto_post_process: null argument");
+    for (uint64_t i = 0; i < n; ++i)
+        post_processing(profile->tonemap, v3(accum[3 * i], accum[3 * i + 1], accum[3 * i + 2]) / (float)profile->samples,
+                        rgb8 + 3 * i);
+    return PT_OK;
+}
+
+int pto_trace_rays_all(const pto_scene* s, const float* rays, uint64_t n, uint32_t max_hits, pt_hit* out,
+                       uint32_t* counts) {
+    if (!s || !rays || !out || !counts) return set_err(PT_ERR_INVALID, "pto_trace_rays_all: null argument");
+#pragma omp parallel
+    {
+        CastScratch sc;
+        uint64_t errs = 0;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t i = 0; i < (int64_t)n; ++i) {
+            Ray r{v3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5])};
+            ray_cast(*s, r, sc, &errs);
+            uint32_t k = (uint32_t)std::min<size_t>(sc.hits.size(), max_hits);
+            counts[i] = (uint32_t)sc.hits.size();
+            for (uint32_t j = 0; j < k; ++j) {
+                const Hit& h = sc.hits[j];
+                pt_hit& o = out[(size_t)i * max_hits + j];
+                o.prim = h.prim;
+                o.flags = h.flags;
+                o.dist = h.dist;
+                o.u = h.sphere ? 0.f : h.u;
+                o.v = h.sphere ? 0.f : h.v;
+            }
+            for (uint32_t j = k; j < max_hits; ++j) out[(size_t)i * max_hits + j] = pt_hit{-1, 0, 0.f, 0.f, 0.f};
+        }
+    }
+    return PT_OK;
+}
+
+int pto_intersect_triangles(const float* rays, const float* tris, uint64_t n, pt_hit* out) {
+    if (!rays || !tris || !out) return set_err(PT_ERR_INVALID, "pto_intersect_triangles: null argument");
+    for (uint64_t i = 0; i < n; ++i) {
+        Triangle tr{};
+        for (int k = 0; k < 3; ++k) tr.v[k].position = v3(tris[9 * i + 3 * k], tris[9 * i + 3 * k + 1], tris[9 * i + 3 * k + 2]);
+        tr.v[1].tex_coords = {1.f, 0.f};  // triangle.rs:165-184
+        tr.v[2].tex_coords = {0.f, 1.f};
+        Ray r{v3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5])};
+        Hit h;
+        if (intersect_triangle(tr, r, &h)) {
+            out[i].prim = 0;
+            out[i].flags = h.is_backface ? 1 : 0;
+            out[i].dist = h.dist;
+            out[i].u = h.tex_coords.x;  // the unit test compares tex_coords (triangle.rs:214-216)
+            out[i].v = h.tex_coords.y;
+        } else {
+            out[i] = pt_hit{-1, 0, 0.f, 0.f, 0.f};
+        }
+    }
+    return PT_OK;
+}
+
+int pto_rng_words(const uint64_t* seeds, uint64_t n_seeds, uint32_t n_words, uint32_t* out) {
+    if (!seeds || !out) return set_err(PT_ERR_INVALID, "pto_rng_words: null argument");
+    for (uint64_t i = 0; i < n_seeds; ++i) {
+        StdRng rng(seeds[i]);
+        for (uint32_t w = 0; w < n_words; ++w) out[i * n_words + w] = rng.next_u32();
+    }
+    return PT_OK;
+}
+
+int pto_eval_math(int fn, const float* x, uint64_t n, float* out) {
+    if (!x || !out) return set_err(PT_ERR_INVALID, "pto_eval_math: null argument");
+    const float inv_gamma = 1.f / 2.2f;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        switch (fn) {
+            case 0: out[i] = powf(x[i], inv_gamma); break;
+            case 1: out[i] = acosf(x[i]); break;
+            case 2: out[i] = sinf(x[i]); break;
+            case 3: out[i] = cosf(x[i]); break;
+            case 4: out[i] = powf(x[i], 2.2f); break;
+            case 5: out[i] = tanf(x[i]); break;
+            default: out[i] = NAN;
+        }
+    }
+    return PT_OK;
+}
+
+int pto_primary_ray(const pto_scene* s, const pt_profile* profile, uint64_t pixel, uint32_t sample, float* out6) {
+    if (!s || !profile || !out6) return set_err(PT_ERR_INVALID, "pto_primary_ray: null argument");
+    StdRng rng((uint64_t)sample + pixel * (uint64_t)profile->samples);
+    Ray r = primary_ray(*s, *profile, pixel, rng);
+    out6[0] = r.origin.x;
+    out6[1] = r.origin.y;
+    out6[2] = r.origin.z;
+    out6[3] = r.direction.x;
+    out6[4] = r.direction.y;
+    out6[5] = r.direction.z;
+    return PT_OK;
+}
+
+}  // extern "C"

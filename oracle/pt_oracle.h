@@ -1,0 +1,79 @@
+/*
+ * pt_oracle.h — C API of the CPU oracle (TEST INFRASTRUCTURE, not product).
+ *
+ * A scalar-f32 restatement of the reference's per-pixel sampling path
+ * (flomonster/path-tracer, src/renderer/ and src/scene/internal/), used
+ * only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as
+ * the checker / CPU baseline.  Nothing in the product path may call it.
+ *
+ * Parity pin: this code reproduces six of the reference's seven golden
+ * SHA-1 image hashes bit-exactly (src/main.rs:104,112,120,128,136,144) and all
+ * 6 024 Möller–Trumbore vectors (tests/moller_trumbore/{hit,miss}_tests.yml); see
+ * tests/test_oracle_golden.py.  white_furnace_direct (src/main.rs:162) is not
+ * reproducible — that one hash is "parity unpinned".
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include "ptgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pto_scene pto_scene;
+
+/* mode bits for pto_scene_create */
+enum {
+    PTO_BRUTE_FORCE = 0, /* test every primitive of every model (literal)      */
+    PTO_BVH = 1          /* AABB-tree candidate filter standing in for
+                            kdtree-ray (result-neutral)           */
+};
+
+int pto_scene_create(const pt_scene_desc* desc, int mode, pto_scene** out);
+void pto_scene_destroy(pto_scene* s);
+
+typedef struct pto_stats {
+    uint64_t samples;
+    uint64_t segments;      /* ray_cast calls from render_pixel                */
+    uint64_t shadow_rays;   /* ray_cast calls from get_light_info              */
+    uint64_t shaded_hits;   /* SurfaceInfo evaluations in the alpha walk       */
+    uint64_t rng_draws;
+    uint64_t max_draws_per_sample;
+    uint64_t numeric_errors; /* NaN distances / sphere asserts (reference panics) */
+} pto_stats;
+
+/* Renderer::render for pixel indices [pixel_begin, pixel_end) (global
+ * index i = x + y*W; pixel_end == 0 means W*H).  Outputs are indexed from
+ * pixel_begin.  threads <= 0 uses every core (OpenMP). */
+int pto_render(const pto_scene* s, const pt_profile* profile, uint64_t pixel_begin,
+               uint64_t pixel_end, int threads, uint8_t* rgb8, float* accum, pto_stats* stats);
+
+/* Renderer::post_processing on n accumulated pixels (accum = sum over samples). */
+int pto_post_process(const pt_profile* profile, const float* accum, uint64_t n, uint8_t* rgb8);
+
+/* ray_cast (renderer/utils.rs:11-21): up to max_hits sorted hits per ray. */
+int pto_trace_rays_all(const pto_scene* s, const float* rays, uint64_t n, uint32_t max_hits,
+                       pt_hit* out, uint32_t* counts);
+
+/* Triangle::intersect (internal/triangle.rs:37-82) with the unit-test uv
+ * convention (tex_coords == (u, v), triangle.rs:165-184). */
+int pto_intersect_triangles(const float* rays, const float* tris, uint64_t n, pt_hit* out);
+
+/* StdRng::seed_from_u64(seed) -> first n_words of next_u32(). */
+int pto_rng_words(const uint64_t* seeds, uint64_t n_seeds, uint32_t n_words, uint32_t* out);
+
+/* libm as the reference calls it: fn 0 powf(x, 1/2.2f), 1 acosf, 2 sinf, 3 cosf. */
+int pto_eval_math(int fn, const float* x, uint64_t n, float* out);
+
+/* The primary ray of (pixel i, sample s) and the RNG draws it consumed
+ * (renderer/mod.rs:107-124): out = origin3, direction3. */
+int pto_primary_ray(const pto_scene* s, const pt_profile* profile, uint64_t pixel, uint32_t sample,
+                    float* out6);
+
+const char* pto_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

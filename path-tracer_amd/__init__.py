@@ -1,0 +1,358 @@
+"""ctypes view of the C ABI (include/ptgpu.h, include/pthost.h).
+
+The product is the C/HIP code under ``csrc/`` and ``host/``; this module only
+mirrors the structs and loads the shared libraries so that tests, bench.py and
+__graft_entry__ can call through the same C ABI a Rust host would bind
+(INTEGRATION.md).  The directory name contains a hyphen, so it is imported as
+``path_tracer_amd`` through ``__graft_entry__.load_package()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+ROOT = PKG_DIR.parent
+
+PT_OK = 0
+PT_MODEL_MESH, PT_MODEL_SPHERE = 0, 1
+PT_LIGHT_POINT, PT_LIGHT_DIRECTIONAL = 0, 1
+PT_TONEMAP_REINHARD, PT_TONEMAP_FILMIC, PT_TONEMAP_ACES = 0, 1, 2
+PT_FLAG_TIMING, PT_FLAG_COUNTERS = 1, 2
+TONEMAPS = {"REINHARD": 0, "FILMIC": 1, "ACES": 2}
+
+
+class Texture(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("channels", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("albedo", C.c_float * 3), ("emissive", C.c_float * 3), ("opacity", C.c_float),
+                ("metalness", C.c_float), ("roughness", C.c_float), ("ior", C.c_float),
+                ("tex_albedo", C.c_int32), ("tex_emissive", C.c_int32), ("tex_opacity", C.c_int32),
+                ("tex_metalness", C.c_int32), ("tex_roughness", C.c_int32), ("tex_normal", C.c_int32)]
+
+
+class Model(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("material", C.c_int32), ("tri_first", C.c_uint32),
+                ("tri_count", C.c_uint32), ("center", C.c_float * 3), ("radius", C.c_float)]
+
+
+class Light(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("vec", C.c_float * 3), ("color", C.c_float * 3), ("size", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("transform", C.c_float * 16), ("fov", C.c_float), ("zfar", C.c_float), ("znear", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_models", C.c_uint32), ("n_materials", C.c_uint32), ("n_textures", C.c_uint32),
+                ("n_lights", C.c_uint32), ("n_triangles", C.c_uint64), ("n_texel_bytes", C.c_uint64),
+                ("models", C.POINTER(Model)), ("materials", C.POINTER(Material)),
+                ("textures", C.POINTER(Texture)), ("lights", C.POINTER(Light)),
+                ("triangles", C.POINTER(C.c_float)), ("texels", C.POINTER(C.c_uint8)),
+                ("camera", Camera), ("background", C.c_float * 3), ("_pad", C.c_uint32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32),
+                ("bounces", C.c_uint32), ("brdf", C.c_int32), ("tonemap", C.c_int32)]
+
+    @classmethod
+    def make(cls, width=1920, height=1080, samples=64, bounces=4, tonemap="FILMIC"):
+        return cls(width, height, samples, bounces, 0, TONEMAPS[tonemap] if isinstance(tonemap, str) else tonemap)
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_uint32, C.c_uint32, C.c_void_p)
+
+
+class Opts(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("device", C.c_int32), ("shard_rank", C.c_uint32),
+                ("shard_count", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
+                ("sample_batch", C.c_uint32), ("_pad", C.c_uint32), ("progress", PROGRESS_FN),
+                ("progress_user", C.c_void_p)]
+
+    @classmethod
+    def make(cls, flags=0, device=-1, shard_rank=0, shard_count=1, tile_w=0, tile_h=0, sample_batch=0):
+        return cls(flags, device, shard_rank, shard_count, tile_w, tile_h, sample_batch, 0,
+                   C.cast(None, PROGRESS_FN), None)
+
+
+class Hit(C.Structure):
+    _fields_ = [("prim", C.c_int32), ("flags", C.c_int32), ("dist", C.c_float), ("u", C.c_float),
+                ("v", C.c_float)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("launches", C.c_uint32), ("integrate_ms", C.c_float), ("postprocess_ms", C.c_float),
+                ("total_ms", C.c_float)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "shadow_rays", "nodes_visited",
+                                          "tris_tested", "shaded_hits", "rng_draws", "restarts")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("n_prims", C.c_uint64), ("n_kd_nodes", C.c_uint64), ("n_kd_leaves", C.c_uint64),
+                ("n_leaf_refs", C.c_uint64), ("kd_depth", C.c_uint32), ("has_translucent", C.c_uint32),
+                ("kd_build_seconds", C.c_float), ("upload_seconds", C.c_float), ("device_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class KdNode(C.Structure):
+    _fields_ = [("w0", C.c_uint32), ("w1", C.c_uint32)]
+
+
+class KdTree(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_refs", C.c_uint64), ("n_leaves", C.c_uint64),
+                ("depth", C.c_uint32), ("_pad", C.c_uint32), ("bounds_min", C.c_float * 3),
+                ("bounds_max", C.c_float * 3), ("nodes", C.POINTER(KdNode)), ("refs", C.POINTER(C.c_uint32)),
+                ("build_seconds", C.c_double)]
+
+
+class OracleStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "shadow_rays", "shaded_hits", "rng_draws",
+                                          "max_draws_per_sample", "numeric_errors")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+_host = None
+_gpu = None
+
+# Every symbol include/pthost.h declares (tests check they are all exported).
+HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_scene_generate_ps5",
+                "pth_scene_save_isf", "pth_profile_load", "pth_profile_parse", "pth_png_read",
+                "pth_png_decode", "pth_png_write_rgb8", "pth_free", "pth_prim_count", "pth_kd_build",
+                "pth_kd_free", "pth_last_error"]
+# Every symbol include/ptgpu.h declares.
+GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_local_pixel_count", "pt_local_pixel_map",
+               "pt_render", "pt_render_device", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
+               "pt_scene_get_info", "pt_trace_rays", "pt_trace_rays_all", "pt_intersect_triangles",
+               "pt_rng_words", "pt_eval_math", "pt_last_error", "pt_version"]
+
+
+def host_lib():
+    """libpthost.so: loader, profile, PNG, generator, KD builder (no HIP)."""
+    global _host
+    if _host is None:
+        path = PKG_DIR / "libpthost.so"
+        if not path.exists():
+            raise PtError(-2, f"{path} is missing: run `make host` (or __graft_entry__.build())")
+        L = C.CDLL(str(path))
+        L.pth_scene_load_isf.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.pth_scene_free.argtypes = [C.c_void_p]
+        L.pth_scene_free.restype = None
+        L.pth_scene_desc.argtypes = [C.c_void_p]
+        L.pth_scene_desc.restype = C.POINTER(SceneDesc)
+        L.pth_scene_generate_ps5.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.pth_scene_save_isf.argtypes = [C.c_void_p, C.c_char_p]
+        L.pth_profile_load.argtypes = [C.c_char_p, C.POINTER(Profile)]
+        L.pth_profile_parse.argtypes = [C.c_char_p, C.POINTER(Profile)]
+        L.pth_png_read.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.POINTER(C.c_uint8))]
+        L.pth_png_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8))]
+        L.pth_png_write_rgb8.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.pth_free.argtypes = [C.c_void_p]
+        L.pth_free.restype = None
+        L.pth_prim_count.argtypes = [C.POINTER(SceneDesc)]
+        L.pth_prim_count.restype = C.c_uint64
+        L.pth_kd_build.argtypes = [C.POINTER(SceneDesc), C.POINTER(KdTree)]
+        L.pth_kd_free.argtypes = [C.POINTER(KdTree)]
+        L.pth_kd_free.restype = None
+        L.pth_last_error.restype = C.c_char_p
+        _host = L
+    return _host
+
+
+def gpu_lib():
+    """libptgpu.so: the HIP integrator behind the C ABI.  Fails loudly when missing."""
+    global _gpu
+    if _gpu is None:
+        path = PKG_DIR / "libptgpu.so"
+        if not path.exists():
+            raise PtError(-4, f"{path} is missing: the HIP extension was not built "
+                              "(run `make gpu` or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(str(path))
+        vp = C.c_void_p
+        L.pt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(vp)]
+        L.pt_scene_destroy.argtypes = [vp]
+        L.pt_scene_destroy.restype = None
+        L.pt_local_pixel_count.argtypes = [C.POINTER(Profile), C.POINTER(Opts)]
+        L.pt_local_pixel_count.restype = C.c_uint64
+        L.pt_local_pixel_map.argtypes = [C.POINTER(Profile), C.POINTER(Opts), vp]
+        L.pt_render.argtypes = [vp, C.POINTER(Profile), C.POINTER(Opts), vp, vp]
+        L.pt_render_device.argtypes = [vp, C.POINTER(Profile), C.POINTER(Opts), vp, vp, vp]
+        L.pt_assemble_tiles.argtypes = [C.POINTER(Profile), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                        C.c_uint32, vp, vp, vp]
+        L.pt_get_timing.argtypes = [vp, C.POINTER(Timing)]
+        L.pt_get_counters.argtypes = [vp, C.POINTER(Counters)]
+        L.pt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
+        L.pt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp]
+        L.pt_trace_rays_all.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
+        L.pt_intersect_triangles.argtypes = [C.c_int, vp, vp, C.c_uint64, vp]
+        L.pt_rng_words.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]
+        L.pt_eval_math.argtypes = [C.c_int, C.c_int, vp, C.c_uint64, vp]
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_version.restype = C.c_char_p
+        _gpu = L
+    return _gpu
+
+
+def check_host(rc):
+    if rc != PT_OK:
+        raise PtError(rc, host_lib().pth_last_error().decode(errors="replace"))
+
+
+def check_gpu(rc):
+    if rc != PT_OK:
+        raise PtError(rc, gpu_lib().pt_last_error().decode(errors="replace"))
+
+
+class HostScene:
+    """Owned pth_scene handle (ISF file or generated)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+        self.desc = host_lib().pth_scene_desc(handle)
+
+    @classmethod
+    def load_isf(cls, path):
+        h = C.c_void_p()
+        check_host(host_lib().pth_scene_load_isf(os.fsencode(str(path)), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def generate_ps5(cls, target_tris, seed=0, flags=0):
+        h = C.c_void_p()
+        check_host(host_lib().pth_scene_generate_ps5(target_tris, seed, flags, C.byref(h)))
+        return cls(h)
+
+    def save_isf(self, directory):
+        check_host(host_lib().pth_scene_save_isf(self.handle, os.fsencode(str(directory))))
+
+    @property
+    def n_triangles(self):
+        return int(self.desc.contents.n_triangles)
+
+    @property
+    def n_prims(self):
+        return int(host_lib().pth_prim_count(self.desc))
+
+    def close(self):
+        if self.handle:
+            host_lib().pth_scene_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_profile(path=None, text=None):
+    p = Profile()
+    if text is not None:
+        check_host(host_lib().pth_profile_parse(text.encode(), C.byref(p)))
+    else:
+        check_host(host_lib().pth_profile_load(os.fsencode(str(path)) if path else None, C.byref(p)))
+    return p
+
+
+class GpuScene:
+    """Device-resident scene (pt_scene_create / pt_scene_destroy)."""
+
+    def __init__(self, host_scene: HostScene, device=0):
+        self.lib = gpu_lib()
+        self.handle = C.c_void_p()
+        self._host = host_scene
+        check_gpu(self.lib.pt_scene_create(host_scene.desc, device, C.byref(self.handle)))
+
+    def info(self):
+        i = SceneInfo()
+        check_gpu(self.lib.pt_scene_get_info(self.handle, C.byref(i)))
+        return i
+
+    def render(self, profile, opts=None):
+        """Host-buffer render: returns (rgb8 [n,3] uint8, accum [n,3] float32)."""
+        import numpy as np
+        opts = opts or Opts.make()
+        n = int(self.lib.pt_local_pixel_count(C.byref(profile), C.byref(opts)))
+        rgb = np.empty((n, 3), np.uint8)
+        acc = np.empty((n, 3), np.float32)
+        check_gpu(self.lib.pt_render(self.handle, C.byref(profile), C.byref(opts), rgb.ctypes.data, acc.ctypes.data))
+        return rgb, acc
+
+    def render_device(self, profile, opts, d_rgb8, d_accum, stream=0):
+        check_gpu(self.lib.pt_render_device(self.handle, C.byref(profile), C.byref(opts), d_rgb8, d_accum, stream))
+
+    def timing(self):
+        t = Timing()
+        check_gpu(self.lib.pt_get_timing(self.handle, C.byref(t)))
+        return t
+
+    def counters(self):
+        c = Counters()
+        check_gpu(self.lib.pt_get_counters(self.handle, C.byref(c)))
+        return c
+
+    def trace(self, rays):
+        import numpy as np
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros(len(rays), dtype=HIT_DTYPE)
+        check_gpu(self.lib.pt_trace_rays(self.handle, rays.ctypes.data, len(rays), out.ctypes.data))
+        return out
+
+    def trace_all(self, rays, max_hits=8):
+        import numpy as np
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros((len(rays), max_hits), dtype=HIT_DTYPE)
+        counts = np.zeros(len(rays), np.uint32)
+        check_gpu(self.lib.pt_trace_rays_all(self.handle, rays.ctypes.data, len(rays), max_hits,
+                                             out.ctypes.data, counts.ctypes.data))
+        return out, counts
+
+    def close(self):
+        if self.handle:
+            self.lib.pt_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+try:
+    import numpy as _np
+    HIT_DTYPE = _np.dtype([("prim", "<i4"), ("flags", "<i4"), ("dist", "<f4"), ("u", "<f4"), ("v", "<f4")])
+except Exception:  # pragma: no cover
+    HIT_DTYPE = None
+
+
+def local_pixel_map(profile, opts):
+    import numpy as np
+    lib = gpu_lib()
+    n = int(lib.pt_local_pixel_count(C.byref(profile), C.byref(opts)))
+    out = np.empty(n, np.uint32)
+    check_gpu(lib.pt_local_pixel_map(C.byref(profile), C.byref(opts), out.ctypes.data))
+    return out

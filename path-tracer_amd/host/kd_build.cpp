@@ -1,0 +1,287 @@
+// SAH KD-tree builder over every primitive of the scene.
+//
+// Replaces the third-party `kdtree-ray` crate the reference builds its two
+// tree levels with (src/scene/internal/mod.rs:42 — scene tree over model
+// AABBs; src/scene/internal/model.rs:96 — per-mesh tree over triangle AABBs;
+// Bounded impls: triangle.rs:84-122, model.rs:76-86).  The reference uses the
+// tree only as a candidate filter in front of Triangle::intersect /
+// Model::intersect (src/renderer/utils.rs:11-21), so any structure that
+// never drops a primitive whose intersect() succeeds yields the same image
+// (SURVEY §0.2).  This builder therefore uses ONE tree over all triangles
+// and spheres, keyed by the global primitive id (model order, triangle order
+// inside a model) that also defines the reference's tie order.
+//
+// Robustness rules that keep the "never drop a hit" property:
+//   * primitives are assigned to children by their exact f32 AABB (no
+//     clipping), with closed comparisons, so a primitive touching the split
+//     plane lands on every side it touches;
+//   * split positions are primitive AABB bounds (exact f32 values);
+//   * the device traversal accepts hits outside the current leaf interval
+//     and keeps walking while the next node starts before the best hit
+//     (plus a relative slack), see csrc/pt_kernels.hip.
+//
+// Cost model: surface-area heuristic with exact sweep over AABB edges
+// (after Wald & Havran / pbrt's KdTreeAccel), traversal cost 1, empty bonus
+// 0.5; intersection cost and leaf size are tunable through PT_KD_ISECT_COST
+// / PT_KD_MAX_LEAF for experiments.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <memory>
+
+#include "host_common.hpp"
+
+namespace pth {
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+};
+
+struct Edge {
+    float t;
+    uint32_t key;  // prim << 1 | is_end
+};
+
+struct Sub {
+    std::vector<pth_kd_node> nodes;
+    std::vector<uint32_t> refs;
+    uint32_t depth = 0;
+    uint64_t leaves = 0;
+};
+
+struct Builder {
+    const std::vector<Box>& boxes;
+    float isect_cost;
+    float trav_cost = 1.0f;
+    float empty_bonus = 0.5f;
+    uint32_t max_leaf;
+    int par_levels;
+
+    void leaf(Sub& out, const std::vector<uint32_t>& prims, uint32_t level) {
+        pth_kd_node n;
+        n.w0 = (uint32_t)out.refs.size();
+        n.w1 = ((uint32_t)prims.size() << 2) | 3u;
+        out.nodes.push_back(n);
+        out.refs.insert(out.refs.end(), prims.begin(), prims.end());
+        out.depth = std::max(out.depth, level);
+        out.leaves++;
+    }
+
+    void build(Sub& out, const Box& nb, std::vector<uint32_t>&& prims, int depth_left, int bad,
+               uint32_t level) {
+        const size_t n = prims.size();
+        if (n <= max_leaf || depth_left == 0) {
+            leaf(out, prims, level);
+            return;
+        }
+        // SAH sweep
+        float d[3] = {nb.mx[0] - nb.mn[0], nb.mx[1] - nb.mn[1], nb.mx[2] - nb.mn[2]};
+        float total_sa = 2.f * (d[0] * d[1] + d[0] * d[2] + d[1] * d[2]);
+        float inv_total_sa = total_sa > 0 ? 1.f / total_sa : 0.f;
+        float old_cost = isect_cost * (float)n;
+        float best_cost = INFINITY;
+        int best_axis = -1;
+        size_t best_offset = 0;
+        std::vector<Edge> edges(2 * n), best_edges;
+        int axis = d[0] > d[1] ? (d[0] > d[2] ? 0 : 2) : (d[1] > d[2] ? 1 : 2);
+        for (int retry = 0; retry < 3; ++retry) {
+            for (size_t i = 0; i < n; ++i) {
+                const Box& b = boxes[prims[i]];
+                edges[2 * i] = {b.mn[axis], prims[i] << 1};
+                edges[2 * i + 1] = {b.mx[axis], (prims[i] << 1) | 1u};
+            }
+            std::sort(edges.begin(), edges.end(), [](const Edge& a, const Edge& b) {
+                if (a.t != b.t) return a.t < b.t;
+                return (a.key & 1u) < (b.key & 1u);  // starts before ends
+            });
+            size_t n_below = 0, n_above = n;
+            int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+            for (size_t i = 0; i < 2 * n; ++i) {
+                if (edges[i].key & 1u) --n_above;
+                float t = edges[i].t;
+                if (t > nb.mn[axis] && t < nb.mx[axis]) {
+                    float below_sa = 2.f * (d[a1] * d[a2] + (t - nb.mn[axis]) * (d[a1] + d[a2]));
+                    float above_sa = 2.f * (d[a1] * d[a2] + (nb.mx[axis] - t) * (d[a1] + d[a2]));
+                    float pb = below_sa * inv_total_sa, pa = above_sa * inv_total_sa;
+                    float eb = (n_above == 0 || n_below == 0) ? empty_bonus : 0.f;
+                    float cost = trav_cost + isect_cost * (1.f - eb) * (pb * (float)n_below + pa * (float)n_above);
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = axis;
+                        best_offset = i;
+                    }
+                }
+                if (!(edges[i].key & 1u)) ++n_below;
+            }
+            if (best_axis != -1) {
+                best_edges.swap(edges);  // sorted edges of the winning axis
+                break;
+            }
+            axis = (axis + 1) % 3;  // no split plane strictly inside the node: try the next axis
+        }
+        if (best_cost > old_cost) ++bad;
+        if ((best_cost > 4.f * old_cost && n < 16) || best_axis == -1 || bad == 3) {
+            leaf(out, prims, level);
+            return;
+        }
+        // classify
+        std::vector<uint32_t> below, above;
+        below.reserve(n);
+        above.reserve(n);
+        for (size_t i = 0; i < best_offset; ++i)
+            if (!(best_edges[i].key & 1u)) below.push_back(best_edges[i].key >> 1);
+        for (size_t i = best_offset + 1; i < 2 * n; ++i)
+            if (best_edges[i].key & 1u) above.push_back(best_edges[i].key >> 1);
+        float split = best_edges[best_offset].t;
+        std::vector<Edge>().swap(edges);
+        std::vector<Edge>().swap(best_edges);
+        std::vector<uint32_t>().swap(prims);
+        // leaf refs keep ascending primitive order (deterministic tie order)
+        std::sort(below.begin(), below.end());
+        std::sort(above.begin(), above.end());
+
+        Box bb = nb, ab = nb;
+        bb.mx[best_axis] = split;
+        ab.mn[best_axis] = split;
+
+        size_t me = out.nodes.size();
+        out.nodes.push_back({0, 0});
+        uint32_t above_idx;
+        if ((int)level < par_levels && n > 20000) {
+            auto fut = std::async(std::launch::async, [&, this]() {
+                auto sub = std::make_unique<Sub>();
+                build(*sub, ab, std::move(above), depth_left - 1, bad, level + 1);
+                return sub;
+            });
+            build(out, bb, std::move(below), depth_left - 1, bad, level + 1);
+            std::unique_ptr<Sub> sub = fut.get();
+            above_idx = (uint32_t)out.nodes.size();
+            uint32_t ref_base = (uint32_t)out.refs.size();
+            out.nodes.reserve(out.nodes.size() + sub->nodes.size());
+            for (pth_kd_node nd : sub->nodes) {
+                if ((nd.w1 & 3u) == 3u) nd.w0 += ref_base;
+                else nd.w1 = (((nd.w1 >> 2) + above_idx) << 2) | (nd.w1 & 3u);
+                out.nodes.push_back(nd);
+            }
+            out.refs.insert(out.refs.end(), sub->refs.begin(), sub->refs.end());
+            out.depth = std::max(out.depth, sub->depth);
+            out.leaves += sub->leaves;
+        } else {
+            build(out, bb, std::move(below), depth_left - 1, bad, level + 1);
+            above_idx = (uint32_t)out.nodes.size();
+            build(out, ab, std::move(above), depth_left - 1, bad, level + 1);
+        }
+        if (above_idx >= (1u << 30)) fail(PT_ERR_UNSUPPORTED, "KD-tree has too many nodes");
+        pth_kd_node nd;
+        memcpy(&nd.w0, &split, 4);
+        nd.w1 = (above_idx << 2) | (uint32_t)best_axis;
+        out.nodes[me] = nd;
+    }
+};
+
+float env_float(const char* name, float dflt) {
+    const char* v = getenv(name);
+    return v && *v ? (float)atof(v) : dflt;
+}
+
+}  // namespace
+
+void prim_boxes(const pt_scene_desc& d, std::vector<Box>& boxes) {
+    boxes.clear();
+    boxes.reserve(pth_prim_count(&d));
+    for (uint32_t m = 0; m < d.n_models; ++m) {
+        const pt_model& mo = d.models[m];
+        if (mo.kind == PT_MODEL_MESH) {
+            for (uint32_t t = 0; t < mo.tri_count; ++t) {
+                const float* v = d.triangles + (size_t)(mo.tri_first + t) * 24;
+                Box b;
+                for (int a = 0; a < 3; ++a) {
+                    // Triangle::bound (triangle.rs:84-122)
+                    b.mn[a] = std::min(std::min(v[a], v[8 + a]), v[16 + a]);
+                    b.mx[a] = std::max(std::max(v[a], v[8 + a]), v[16 + a]);
+                }
+                boxes.push_back(b);
+            }
+        } else {
+            Box b;  // Model::bound for spheres (model.rs:80-84)
+            for (int a = 0; a < 3; ++a) {
+                b.mn[a] = mo.center[a] - mo.radius;
+                b.mx[a] = mo.center[a] + mo.radius;
+            }
+            boxes.push_back(b);
+        }
+    }
+}
+
+static void kd_build(const pt_scene_desc& d, pth_kdtree& out) {
+    auto t0 = std::chrono::steady_clock::now();
+    memset(&out, 0, sizeof out);
+    std::vector<Box> boxes;
+    prim_boxes(d, boxes);
+    size_t n = boxes.size();
+    if (n >= (1u << 30)) fail(PT_ERR_UNSUPPORTED, "too many primitives for the KD-tree (%zu)", n);
+    Box root;
+    for (int a = 0; a < 3; ++a) {
+        root.mn[a] = INFINITY;
+        root.mx[a] = -INFINITY;
+    }
+    for (const Box& b : boxes)
+        for (int a = 0; a < 3; ++a) {
+            if (!(b.mn[a] == b.mn[a]) || !(b.mx[a] == b.mx[a]))
+                fail(PT_ERR_NUMERIC, "NaN vertex coordinate in scene");
+            root.mn[a] = std::min(root.mn[a], b.mn[a]);
+            root.mx[a] = std::max(root.mx[a], b.mx[a]);
+        }
+    if (n == 0)
+        for (int a = 0; a < 3; ++a) root.mn[a] = root.mx[a] = 0.f;
+
+    Builder b{boxes, env_float("PT_KD_ISECT_COST", 24.f)};
+    b.max_leaf = (uint32_t)env_float("PT_KD_MAX_LEAF", 2.f);
+    b.par_levels = (int)env_float("PT_KD_PAR_LEVELS", 4.f);
+    int max_depth = n ? (int)std::lround(8 + 1.3 * std::log2((double)n)) : 0;
+    if (max_depth > 62) max_depth = 62;  // device traversal stack bound
+    max_depth = (int)env_float("PT_KD_MAX_DEPTH", (float)max_depth);
+
+    Sub sub;
+    std::vector<uint32_t> prims(n);
+    for (size_t i = 0; i < n; ++i) prims[i] = (uint32_t)i;
+    b.build(sub, root, std::move(prims), max_depth, 0, 0);
+
+    out.n_nodes = sub.nodes.size();
+    out.n_refs = sub.refs.size();
+    out.n_leaves = sub.leaves;
+    out.depth = sub.depth;
+    memcpy(out.bounds_min, root.mn, sizeof root.mn);
+    memcpy(out.bounds_max, root.mx, sizeof root.mx);
+    out.nodes = (pth_kd_node*)malloc(std::max<size_t>(1, sub.nodes.size()) * sizeof(pth_kd_node));
+    out.refs = (uint32_t*)malloc(std::max<size_t>(1, sub.refs.size()) * sizeof(uint32_t));
+    if (!out.nodes || !out.refs) throw std::bad_alloc();
+    memcpy(out.nodes, sub.nodes.data(), sub.nodes.size() * sizeof(pth_kd_node));
+    memcpy(out.refs, sub.refs.data(), sub.refs.size() * sizeof(uint32_t));
+    out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace pth
+
+extern "C" {
+
+int pth_kd_build(const pt_scene_desc* desc, pth_kdtree* out) {
+    return pth::guarded([&] {
+        if (!desc || !out) pth::fail(PT_ERR_INVALID, "pth_kd_build: null argument");
+        pth::kd_build(*desc, *out);
+    });
+}
+
+void pth_kd_free(pth_kdtree* kd) {
+    if (!kd) return;
+    free(kd->nodes);
+    free(kd->refs);
+    kd->nodes = nullptr;
+    kd->refs = nullptr;
+}
+
+}  // extern "C"

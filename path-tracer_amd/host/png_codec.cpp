@@ -1,0 +1,242 @@
+// Minimal PNG codec on top of zlib (libpng is not in the image).
+//
+// Stands in for the `image` crate calls of the reference:
+//   image::open(path).into_rgb8()  / .into_luma8()   src/scene/internal/texture_bank.rs:33,49
+//   RgbImage::save(path)                              src/main.rs:50
+// Decoding supports every non-interlaced PNG colour type / bit depth and
+// converts like `image` 0.25: gray -> rgb replicates, rgb -> luma uses the
+// integer weights (2126, 7152, 722)/10000, alpha is dropped, 16-bit samples
+// are reduced with (v + 128) / 257, sub-byte gray is scaled to 0..255,
+// palette entries expand to rgb.  Only the 8-bit gray / rgb / palette cases
+// are pinned by reference fixtures (head, alpha_transparency); the rest is
+// "parity unpinned" (SURVEY §4).
+#include <zlib.h>
+
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <vector>
+
+#include "host_common.hpp"
+
+namespace pth {
+namespace {
+
+uint32_t be32(const uint8_t* p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+
+uint8_t paeth(int a, int b, int c) {
+    int p = a + b - c;
+    int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    if (pa <= pb && pa <= pc) return (uint8_t)a;
+    if (pb <= pc) return (uint8_t)b;
+    return (uint8_t)c;
+}
+
+void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32_t* oh,
+            uint8_t** opx) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (len < 8 || memcmp(data, sig, 8) != 0) fail(PT_ERR_PARSE, "not a PNG file");
+    if (want != 1 && want != 3) fail(PT_ERR_INVALID, "want_channels must be 1 or 3");
+    size_t pos = 8;
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    bool seen_ihdr = false, seen_iend = false;
+    while (pos + 12 <= len && !seen_iend) {
+        uint32_t clen = be32(data + pos);
+        const uint8_t* type = data + pos + 4;
+        if (pos + 12 + (size_t)clen > len) fail(PT_ERR_PARSE, "truncated PNG chunk");
+        const uint8_t* body = data + pos + 8;
+        if (!memcmp(type, "IHDR", 4)) {
+            if (clen != 13) fail(PT_ERR_PARSE, "bad IHDR");
+            w = be32(body);
+            h = be32(body + 4);
+            depth = body[8];
+            ctype = body[9];
+            interlace = body[12];
+            seen_ihdr = true;
+        } else if (!memcmp(type, "PLTE", 4)) {
+            plte.assign(body, body + clen);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + clen);
+        } else if (!memcmp(type, "IEND", 4)) {
+            seen_iend = true;
+        }
+        pos += 12 + (size_t)clen;
+    }
+    if (!seen_ihdr || w == 0 || h == 0) fail(PT_ERR_PARSE, "PNG without IHDR");
+    if (interlace) fail(PT_ERR_UNSUPPORTED, "interlaced PNG is not supported");
+    int channels;
+    switch (ctype) {
+        case 0: channels = 1; break;
+        case 2: channels = 3; break;
+        case 3: channels = 1; break;
+        case 4: channels = 2; break;
+        case 6: channels = 4; break;
+        default: fail(PT_ERR_PARSE, "bad PNG colour type %d", ctype);
+    }
+    if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16) ||
+        ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8) || (ctype == 3 && depth > 8))
+        fail(PT_ERR_PARSE, "bad PNG bit depth %d for colour type %d", depth, ctype);
+    if (ctype == 3 && plte.empty()) fail(PT_ERR_PARSE, "palette PNG without PLTE");
+
+    size_t bpp_bits = (size_t)channels * depth;
+    size_t stride = ((size_t)w * bpp_bits + 7) / 8;
+    size_t bpp = bpp_bits < 8 ? 1 : bpp_bits / 8;  // filter byte distance
+    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    uLongf rawlen = raw.size();
+    int zr = uncompress(raw.data(), &rawlen, idat.data(), idat.size());
+    if (zr != Z_OK || rawlen != raw.size()) fail(PT_ERR_PARSE, "PNG inflate failed (%d)", zr);
+
+    // unfilter in place
+    std::vector<uint8_t> zero(stride, 0);
+    for (uint32_t y = 0; y < h; ++y) {
+        uint8_t* row = raw.data() + (stride + 1) * (size_t)y;
+        uint8_t ft = row[0];
+        uint8_t* cur = row + 1;
+        const uint8_t* up = y ? row - stride : zero.data();
+        switch (ft) {
+            case 0: break;
+            case 1:
+                for (size_t i = bpp; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
+                break;
+            case 2:
+                for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + up[i]);
+                break;
+            case 3:
+                for (size_t i = 0; i < stride; ++i) {
+                    int a = i >= bpp ? cur[i - bpp] : 0;
+                    cur[i] = (uint8_t)(cur[i] + ((a + up[i]) >> 1));
+                }
+                break;
+            case 4:
+                for (size_t i = 0; i < stride; ++i) {
+                    int a = i >= bpp ? cur[i - bpp] : 0;
+                    int c = i >= bpp ? up[i - bpp] : 0;
+                    cur[i] = (uint8_t)(cur[i] + paeth(a, up[i], c));
+                }
+                break;
+            default: fail(PT_ERR_PARSE, "bad PNG filter type %d", ft);
+        }
+    }
+
+    uint8_t* out = (uint8_t*)malloc((size_t)w * h * want);
+    if (!out) throw std::bad_alloc();
+    auto sample = [&](const uint8_t* row, size_t idx) -> uint32_t {  // idx = sample index in row
+        if (depth == 8) return row[idx];
+        if (depth == 16) return ((uint32_t)row[2 * idx] << 8) | row[2 * idx + 1];
+        size_t bit = idx * depth;
+        uint32_t v = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1);
+        return v;
+    };
+    auto to8 = [&](uint32_t v) -> uint8_t {
+        if (depth == 8) return (uint8_t)v;
+        if (depth == 16) return (uint8_t)((v + 128) / 257);
+        return (uint8_t)(v * 255 / ((1u << depth) - 1));
+    };
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t* row = raw.data() + (stride + 1) * (size_t)y + 1;
+        for (uint32_t x = 0; x < w; ++x) {
+            uint8_t r, g, b;
+            bool is_gray = false;
+            if (ctype == 0 || ctype == 4) {
+                r = g = b = to8(sample(row, (size_t)x * channels));
+                is_gray = true;
+            } else if (ctype == 3) {
+                uint32_t idx = sample(row, x);
+                if ((size_t)idx * 3 + 2 >= plte.size()) fail(PT_ERR_PARSE, "palette index out of range");
+                r = plte[idx * 3];
+                g = plte[idx * 3 + 1];
+                b = plte[idx * 3 + 2];
+            } else {
+                r = to8(sample(row, (size_t)x * channels));
+                g = to8(sample(row, (size_t)x * channels + 1));
+                b = to8(sample(row, (size_t)x * channels + 2));
+            }
+            uint8_t* o = out + ((size_t)y * w + x) * want;
+            if (want == 3) {
+                o[0] = r;
+                o[1] = g;
+                o[2] = b;
+            } else {
+                o[0] = is_gray ? r : (uint8_t)((2126u * r + 7152u * g + 722u * b) / 10000u);
+            }
+        }
+    }
+    *ow = w;
+    *oh = h;
+    *opx = out;
+}
+
+void put32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24));
+    v.push_back((uint8_t)(x >> 16));
+    v.push_back((uint8_t)(x >> 8));
+    v.push_back((uint8_t)x);
+}
+
+void chunk(std::vector<uint8_t>& out, const char* type, const uint8_t* body, size_t n) {
+    put32(out, (uint32_t)n);
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), body, body + n);
+    uint32_t crc = (uint32_t)crc32(0L, out.data() + start, (uInt)(n + 4));
+    put32(out, crc);
+}
+
+}  // namespace
+}  // namespace pth
+
+extern "C" {
+
+int pth_png_decode(const uint8_t* data, size_t len, uint32_t want_channels, uint32_t* w,
+                   uint32_t* h, uint8_t** pixels) {
+    return pth::guarded([&] {
+        if (!data || !w || !h || !pixels) pth::fail(PT_ERR_INVALID, "pth_png_decode: null argument");
+        pth::decode(data, len, want_channels, w, h, pixels);
+    });
+}
+
+int pth_png_read(const char* path, uint32_t want_channels, uint32_t* w, uint32_t* h,
+                 uint8_t** pixels) {
+    return pth::guarded([&] {
+        if (!path) pth::fail(PT_ERR_INVALID, "pth_png_read: null path");
+        std::ifstream f(path, std::ios::binary);
+        if (!f) pth::fail(PT_ERR_IO, "%s: %s", path, strerror(errno));
+        std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        pth::decode(buf.data(), buf.size(), want_channels, w, h, pixels);
+    });
+}
+
+int pth_png_write_rgb8(const char* path, uint32_t w, uint32_t h, const uint8_t* rgb) {
+    return pth::guarded([&] {
+        if (!path || !rgb || !w || !h) pth::fail(PT_ERR_INVALID, "pth_png_write_rgb8: bad argument");
+        size_t stride = (size_t)w * 3;
+        std::vector<uint8_t> raw((stride + 1) * h);
+        for (uint32_t y = 0; y < h; ++y) {
+            raw[(stride + 1) * y] = 0;
+            memcpy(&raw[(stride + 1) * y + 1], rgb + stride * y, stride);
+        }
+        uLongf clen = compressBound(raw.size());
+        std::vector<uint8_t> comp(clen);
+        if (compress2(comp.data(), &clen, raw.data(), raw.size(), 6) != Z_OK)
+            pth::fail(PT_ERR_IO, "PNG deflate failed");
+        std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+        std::vector<uint8_t> ihdr;
+        pth::put32(ihdr, w);
+        pth::put32(ihdr, h);
+        ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});
+        pth::chunk(out, "IHDR", ihdr.data(), ihdr.size());
+        pth::chunk(out, "IDAT", comp.data(), clen);
+        pth::chunk(out, "IEND", nullptr, 0);
+        std::ofstream f(path, std::ios::binary);
+        if (!f) pth::fail(PT_ERR_IO, "%s: %s", path, strerror(errno));
+        f.write((const char*)out.data(), (std::streamsize)out.size());
+        if (!f) pth::fail(PT_ERR_IO, "%s: write failed", path);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as entry  # noqa: E402
+
+GOLDEN = ROOT / "tests" / "golden"
+SCENES = GOLDEN / "scenes"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pta():
+    return entry.load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return entry.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def scene_cache(pta):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = pta.HostScene.load_isf(SCENES / name / "scene.isf")
+        return cache[name]
+    return get
+
+
+@pytest.fixture(scope="session")
+def gpu_scene_cache(pta, scene_cache):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = pta.GpuScene(scene_cache(name), device=0)
+        return cache[name]
+    return get
