@@ -35,8 +35,13 @@ oracle/libptoracle.so: oracle/pt_oracle.cpp oracle/pt_oracle.h include/ptgpu.h
 
 GPU_SRC := $(wildcard $(PKG)/csrc/*.hip)
 GPU_HDR := $(wildcard $(PKG)/csrc/*.h) $(wildcard $(PKG)/csrc/*.hpp) include/ptgpu.h include/pthost.h
-$(PKG)/libptgpu.so: $(GPU_SRC) $(GPU_HDR) $(HOST_OBJ)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(GPU_SRC) $(HOST_OBJ) -lz -pthread
+GPU_OBJ := $(patsubst $(PKG)/csrc/%.hip,$(BUILD)/gpu/%.o,$(GPU_SRC))
+$(BUILD)/gpu/%.o: $(PKG)/csrc/%.hip $(GPU_HDR)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(PKG)/libptgpu.so: $(GPU_OBJ) $(HOST_OBJ)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(GPU_OBJ) $(HOST_OBJ) -lz -pthread
 
 $(PKG)/path-tracer: $(PKG)/host/cli_main.cpp $(PKG)/libptgpu.so
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG) -lptgpu -Wl,-rpath,'$$ORIGIN'

@@ -1,0 +1,78 @@
+// Device-side scene layout (HBM) shared by the kernels and the host API.
+//
+// All arrays are read-only during a render and sized for one MI355X
+// (288 GB HBM3E): the whole scene, KD-tree and textures are replicated on
+// every GPU.
+//
+//   kd_nodes    8 B / node   pbrt-style KD node (see include/pthost.h)
+//   leaf_prims  48 B / leaf reference, stored leaf after leaf so a leaf's
+//               primitives are one contiguous, 16-B aligned run:
+//                 q0 = (v0.x, v0.y, v0.z, bits(prim_id | kind<<31))
+//                 q1 = (e1.x, e1.y, e1.z, e2.x)      e1 = v1 - v0 (f32, as
+//                 q2 = (e2.y, e2.z, 0, 0)            triangle.rs:43-44 computes it)
+//               spheres: q0 = (c.x, c.y, c.z, bits(prim | 1<<31)), q1.x = radius
+//   prim_attr   64 B / primitive, indexed by global primitive id (shading only):
+//                 a0 = (n0.xyz, uv0.x) a1 = (n1.xyz, uv0.y) a2 = (n2.xyz, uv1.x)
+//                 a3 = (uv1.y, uv2.x, uv2.y, bits(model))
+//               spheres: a0 = (c.xyz, radius), a3.w = bits(model)
+//   prim_pos    48 B / primitive (v0, e1, e2 as in leaf_prims) for the tangent
+//               frame of normal-mapped materials and the test hooks
+//   materials   64 B / model (pt_material as is)
+//   textures    pt_texture table + one u8 texel blob
+//   srgb_lut    256 f32: powf(c/255, 2.2) evaluated by the host libm
+//               (Material::get_albedo, internal/material.rs:132-146)
+#pragma once
+#include <stdint.h>
+
+#include "ptgpu.h"
+
+#define PT_PRIM_SPHERE 0x80000000u
+#define PT_KD_STACK 64
+
+struct DevLight {
+    int32_t kind;
+    float vec[3];
+    float color[3];
+    float _pad;
+};
+
+struct DevScene {
+    const uint2* kd_nodes;
+    const float4* leaf_prims;
+    const float4* prim_attr;
+    const float4* prim_pos;
+    const pt_material* materials;   // indexed by MODEL (material resolved on upload)
+    const pt_texture* textures;
+    const uint8_t* texels;
+    const float* srgb_lut;
+    const DevLight* lights;
+    uint32_t n_lights;
+    uint32_t n_prims;
+    uint32_t n_nodes;
+    uint32_t has_translucent;
+    float bounds_min[3];
+    float bounds_max[3];
+    // camera (internal/camera.rs:36-48): columns of the transform, tan(fov/2) from host tanf
+    float cam_c0[3], cam_c1[3], cam_c2[3], cam_c3[3];
+    float tan_half_fov;
+    float background[3];
+};
+
+struct RenderParams {
+    uint32_t width, height;
+    uint32_t samples;       // profile.samples (seed stride, final division)
+    uint32_t bounces;
+    uint32_t sample_begin;  // this launch renders samples (sample_begin, sample_end], 1-based
+    uint32_t sample_end;
+    int32_t tonemap;
+    // pixel sharding (pt_opts)
+    uint32_t shard_rank, shard_count, tile_w, tile_h;
+    uint32_t tiles_x, tiles_y;
+    uint32_t n_local;       // pixels rendered by this call
+};
+
+// Work counters (PT_FLAG_COUNTERS variant only).
+struct DevCounters {
+    unsigned long long samples, segments, shadow_rays, nodes_visited, tris_tested, shaded_hits, rng_draws,
+        restarts;
+};

@@ -1,0 +1,820 @@
+// libptgpu.so — HIP kernels and the C ABI of include/ptgpu.h (gfx950 only).
+//
+// Kernels
+//   k_render<COUNT>   the integrator: one lane per pixel of this call's shard,
+//                     a wavefront covers an 8x8 pixel block (coherent primary
+//                     rays), samples are looped inside the lane so the f32 sum
+//                     `*pixel += color` keeps the reference's order
+//                     (renderer/mod.rs:105-130)
+//   k_postprocess     Renderer::post_processing (mod.rs:335-353)
+//   k_assemble        scatter all-gathered packed tiles into a row-major image
+//   k_trace / k_trace_all / k_isect / k_rng / k_math   parity-test hooks
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "pt_integrator.h"
+#include "pthost.h"
+
+// ------------------------------------------------------------------ errors
+namespace {
+thread_local std::string g_err;
+
+struct GpuError {
+    int code;
+    std::string msg;
+};
+
+[[noreturn]] void fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw GpuError{code, buf};
+}
+
+#define HIP_CHECK(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) fail(PT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+template <class F>
+int guarded(F&& fn) {
+    try {
+        fn();
+        return PT_OK;
+    } catch (const GpuError& e) {
+        g_err = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_err = "out of host memory";
+        return PT_ERR_INVALID;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return PT_ERR_INVALID;
+    }
+}
+}  // namespace
+
+// ------------------------------------------------------------------ pixel mapping
+// Thread -> pixel.  Grid: one 256-thread workgroup per quarter of a tile_w x
+// tile_h tile (4 wavefronts, each an 8x8 pixel block).  Local tile lt is global
+// tile k = shard_rank + lt * shard_count.
+struct PixelRef {
+    uint32_t x, y;
+    uint32_t global_index;  // x + y*W  (seed formula, mod.rs:107-112)
+    uint32_t out_index;     // position in the packed output
+    bool valid;
+};
+
+__device__ __forceinline__ PixelRef map_pixel(const RenderParams& P, const uint32_t* __restrict__ tile_offsets) {
+    PixelRef r;
+    const uint32_t per_tile = P.tile_w * P.tile_h;
+    const uint32_t blocks_per_tile = per_tile / 256u;
+    uint32_t lt = blockIdx.x / blocks_per_tile;
+    uint32_t q = (blockIdx.x % blocks_per_tile) * 256u + threadIdx.x;
+    uint32_t wave = q >> 6, lane = q & 63u;
+    uint32_t waves_x = P.tile_w >> 3;
+    uint32_t tx = (wave % waves_x) * 8u + (lane & 7u);
+    uint32_t ty = (wave / waves_x) * 8u + (lane >> 3);
+    uint32_t k = P.shard_rank + lt * P.shard_count;
+    uint32_t tile_x = k % P.tiles_x, tile_y = k / P.tiles_x;
+    r.x = tile_x * P.tile_w + tx;
+    r.y = tile_y * P.tile_h + ty;
+    r.valid = tile_y < P.tiles_y && r.x < P.width && r.y < P.height;
+    r.global_index = r.x + r.y * P.width;
+    if (P.shard_count <= 1) {
+        r.out_index = r.global_index;
+    } else {
+        uint32_t cw = min(P.tile_w, P.width - tile_x * P.tile_w);
+        r.out_index = tile_offsets[lt] + ty * cw + tx;
+    }
+    return r;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_render(DevScene S, RenderParams P, const uint32_t* __restrict__ tile_offsets,
+                                                float* __restrict__ accum, DevCounters* __restrict__ ctr) {
+    __shared__ uint32_t slab[16 * PT_RNG_BLOCK];
+    PixelRef px = map_pixel(P, tile_offsets);
+    if (!px.valid) return;
+    const uint32_t tid = threadIdx.x;
+    float* out = accum + (size_t)px.out_index * 3;
+    f3 acc = mk3(0.f, 0.f, 0.f);
+    if (P.sample_begin != 0) acc = mk3(out[0], out[1], out[2]);
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};
+    uint32_t draws = 0;
+    for (uint32_t s = P.sample_begin + 1; s <= P.sample_end; ++s) {
+        PtRng rng;
+        pt_rng_seed(rng, (uint64_t)s + (uint64_t)px.global_index * (uint64_t)P.samples);
+        float r1 = pt_rng_f32(rng, slab, tid);
+        float r2 = pt_rng_f32(rng, slab, tid);
+        f3 o, d;
+        primary_ray(S, px.x, px.y, P.width, P.height, r1, r2, o, d);
+        f3 color = render_path<COUNT>(S, P.bounces, o, d, rng, slab, tid, lc);
+        acc = acc + color;
+        if (COUNT) draws += rng.draws;
+    }
+    out[0] = acc.x;
+    out[1] = acc.y;
+    out[2] = acc.z;
+    if (COUNT) {
+        atomicAdd(&ctr->samples, (unsigned long long)(P.sample_end - P.sample_begin));
+        atomicAdd(&ctr->segments, (unsigned long long)lc.segments);
+        atomicAdd(&ctr->shadow_rays, (unsigned long long)lc.shadow_rays);
+        atomicAdd(&ctr->nodes_visited, (unsigned long long)lc.nodes);
+        atomicAdd(&ctr->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&ctr->shaded_hits, (unsigned long long)lc.shaded);
+        atomicAdd(&ctr->rng_draws, (unsigned long long)draws);
+        atomicAdd(&ctr->restarts, (unsigned long long)lc.restarts);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_postprocess(const float* __restrict__ accum, uint8_t* __restrict__ rgb8,
+                                                     uint32_t n, uint32_t samples, int tonemap_type) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    f3 c = mk3(accum[3 * (size_t)i], accum[3 * (size_t)i + 1], accum[3 * (size_t)i + 2]) / (float)samples;
+    c = tonemap(tonemap_type, c);
+    rgb8[3 * (size_t)i] = as_u8(pt_pow_inv_gamma(c.x) * 255.f);
+    rgb8[3 * (size_t)i + 1] = as_u8(pt_pow_inv_gamma(c.y) * 255.f);
+    rgb8[3 * (size_t)i + 2] = as_u8(pt_pow_inv_gamma(c.z) * 255.f);
+}
+
+// gathered: shard_count slices of slice_pixels packed pixels; rank_tile_offsets[r * max_local + lt]
+__global__ __launch_bounds__(256) void k_assemble(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ image,
+                                                  const uint32_t* __restrict__ rank_tile_offsets, uint32_t max_local,
+                                                  uint32_t width, uint32_t height, uint32_t shard_count,
+                                                  uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x,
+                                                  uint64_t slice_pixels, uint32_t elem_bytes) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= width * height) return;
+    uint32_t x = i % width, y = i / width;
+    uint32_t tile_x = x / tile_w, tile_y = y / tile_h;
+    uint32_t k = tile_y * tiles_x + tile_x;
+    uint32_t r = k % shard_count, lt = k / shard_count;
+    uint32_t cw = min(tile_w, width - tile_x * tile_w);
+    uint64_t src = (uint64_t)r * slice_pixels + rank_tile_offsets[(size_t)r * max_local + lt] +
+                   (uint64_t)(y - tile_y * tile_h) * cw + (x - tile_x * tile_w);
+    const uint8_t* s = gathered + src * elem_bytes;
+    uint8_t* d = image + (uint64_t)i * elem_bytes;
+    for (uint32_t b = 0; b < elem_bytes; ++b) d[b] = s[b];
+}
+
+// ------------------------------------------------------------------ test-hook kernels
+__device__ __forceinline__ void store_hit(pt_hit& o, const RawHit& h) {
+    o.prim = (int32_t)(h.pid & ~PT_PRIM_SPHERE);
+    o.flags = (int32_t)h.flags;
+    o.dist = h.key;
+    o.u = (h.flags & 2u) ? 0.f : h.u;
+    o.v = (h.flags & 2u) ? 0.f : h.v;
+}
+
+__global__ __launch_bounds__(256) void k_trace(DevScene S, const float* __restrict__ rays, uint64_t n,
+                                               pt_hit* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    f3 o = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    f3 d = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};
+    RawHit h;
+    if (next_hit<false>(S, o, d, -INFINITY, 0u, h, lc)) store_hit(out[i], h);
+    else out[i] = pt_hit{-1, 0, 0.f, 0.f, 0.f};
+}
+
+__global__ __launch_bounds__(256) void k_trace_all(DevScene S, const float* __restrict__ rays, uint64_t n,
+                                                   uint32_t max_hits, pt_hit* __restrict__ out,
+                                                   uint32_t* __restrict__ counts) {
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    f3 o = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    f3 d = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};
+    RawHit h;
+    float t_prev = -INFINITY;
+    uint32_t ord_prev = 0, cnt = 0;
+    while (cnt < 4096u && next_hit<false>(S, o, d, t_prev, ord_prev, h, lc)) {
+        if (cnt < max_hits) store_hit(out[i * max_hits + cnt], h);
+        ++cnt;
+        t_prev = h.key;
+        ord_prev = h.ord;
+    }
+    counts[i] = cnt;
+    for (uint32_t j = cnt; j < max_hits; ++j) out[i * max_hits + j] = pt_hit{-1, 0, 0.f, 0.f, 0.f};
+}
+
+__global__ __launch_bounds__(256) void k_isect(const float* __restrict__ rays, const float* __restrict__ tris,
+                                               uint64_t n, pt_hit* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    f3 o = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    f3 d = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    f3 v0 = ld3(tris + 9 * i), v1 = ld3(tris + 9 * i + 3), v2 = ld3(tris + 9 * i + 6);
+    float dist, u, v;
+    bool bf;
+    if (isect_triangle(o, d, v0, v1 - v0, v2 - v0, dist, u, v, bf)) {
+        // tex_coords of the unit-test triangle (uv0=(0,0), uv1=(1,0), uv2=(0,1); triangle.rs:165-184)
+        f2 uv0 = {0.f, 0.f}, uv1 = {1.f, 0.f}, uv2 = {0.f, 1.f};
+        f2 tc = uv0 + u * (uv1 - uv0) + v * (uv2 - uv0);
+        out[i] = pt_hit{0, bf ? 1 : 0, dist, tc.x, tc.y};
+    } else {
+        out[i] = pt_hit{-1, 0, 0.f, 0.f, 0.f};
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rng(const uint64_t* __restrict__ seeds, uint64_t n_seeds, uint32_t n_words,
+                                             uint32_t* __restrict__ out) {
+    __shared__ uint32_t slab[16 * PT_RNG_BLOCK];
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_seeds) return;
+    PtRng rng;
+    pt_rng_seed(rng, seeds[i]);
+    for (uint32_t w = 0; w < n_words; ++w) out[i * n_words + w] = pt_rng_next_u32(rng, slab, threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_math(int fn, const float* __restrict__ x, uint64_t n, float* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i], r;
+    switch (fn) {
+        case 0: r = pt_pow_inv_gamma(v); break;
+        case 1: r = pt_acosf(v); break;
+        case 2: r = pt_sinf(v); break;
+        case 3: r = pt_cosf(v); break;
+        default: r = NAN;
+    }
+    out[i] = r;
+}
+
+// ------------------------------------------------------------------ host side
+namespace {
+
+struct TileMap {
+    uint32_t tile_w, tile_h, tiles_x, tiles_y, count, rank;
+    uint32_t n_local_tiles;
+    uint64_t n_local;
+    std::vector<uint32_t> offsets;  // n_local_tiles + 1 (only used when count > 1)
+};
+
+void normalise_opts(const pt_profile& p, const pt_opts* in, pt_opts& o) {
+    if (in) o = *in;
+    else memset(&o, 0, sizeof o), o.device = -1;
+    if (o.shard_count == 0) o.shard_count = 1;
+    if (o.tile_w == 0) o.tile_w = 32;
+    if (o.tile_h == 0) o.tile_h = 32;
+    if (o.shard_rank >= o.shard_count) fail(PT_ERR_INVALID, "shard_rank %u >= shard_count %u", o.shard_rank, o.shard_count);
+    if ((o.tile_w & 7u) || (o.tile_h & 7u) || ((o.tile_w * o.tile_h) & 255u))
+        fail(PT_ERR_INVALID, "tile_w/tile_h must be multiples of 8 with tile_w*tile_h a multiple of 256");
+    if (p.width == 0 || p.height == 0) fail(PT_ERR_INVALID, "profile resolution must be non-zero");
+    if ((uint64_t)p.width * p.height >= (1ull << 31)) fail(PT_ERR_UNSUPPORTED, "image too large");
+}
+
+TileMap make_tile_map(const pt_profile& p, const pt_opts& o, uint32_t rank) {
+    TileMap m;
+    m.tile_w = o.tile_w;
+    m.tile_h = o.tile_h;
+    m.tiles_x = (p.width + o.tile_w - 1) / o.tile_w;
+    m.tiles_y = (p.height + o.tile_h - 1) / o.tile_h;
+    m.count = o.shard_count;
+    m.rank = rank;
+    uint32_t n_tiles = m.tiles_x * m.tiles_y;
+    m.n_local_tiles = n_tiles > rank ? (n_tiles - rank + m.count - 1) / m.count : 0;
+    m.offsets.resize(m.n_local_tiles + 1);
+    uint64_t off = 0;
+    for (uint32_t lt = 0; lt < m.n_local_tiles; ++lt) {
+        uint32_t k = rank + lt * m.count;
+        uint32_t tx = k % m.tiles_x, ty = k / m.tiles_x;
+        uint32_t cw = std::min(o.tile_w, p.width - tx * o.tile_w);
+        uint32_t ch = std::min(o.tile_h, p.height - ty * o.tile_h);
+        m.offsets[lt] = (uint32_t)off;
+        off += (uint64_t)cw * ch;
+    }
+    m.offsets[m.n_local_tiles] = (uint32_t)off;
+    m.n_local = off;
+    return m;
+}
+
+struct DeviceBuffer {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void ensure(size_t n) {
+        if (n <= bytes) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+    }
+    ~DeviceBuffer() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+}  // namespace
+
+struct pt_scene {
+    int device = 0;
+    DevScene dev{};
+    std::vector<void*> allocations;
+    pt_scene_info info{};
+    mutable pt_timing timing{};
+    mutable pt_counters counters{};
+    mutable DeviceBuffer accum_scratch, tile_table, counter_buf;
+    mutable std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> tile_key{0, 0, 0, 0, 0, 0};
+    mutable std::vector<hipEvent_t> events;
+
+    ~pt_scene() {
+        (void)hipSetDevice(device);
+        for (void* p : allocations) (void)hipFree(p);
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+    template <class T>
+    const T* upload(const T* host, size_t count) {
+        size_t bytes = std::max<size_t>(16, count * sizeof(T));
+        void* d = nullptr;
+        HIP_CHECK(hipMalloc(&d, bytes));
+        allocations.push_back(d);
+        if (count) HIP_CHECK(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+        info.device_bytes += bytes;
+        return (const T*)d;
+    }
+};
+
+namespace {
+
+void select_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) fail(PT_ERR_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device >= n) fail(PT_ERR_DEVICE, "device %d out of range (%d devices)", device, n);
+    if (device >= 0) HIP_CHECK(hipSetDevice(device));
+}
+
+void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
+    select_device(device);
+    int cur = 0;
+    HIP_CHECK(hipGetDevice(&cur));
+    s.device = cur;
+
+    // ---- validate
+    for (uint32_t m = 0; m < d.n_models; ++m) {
+        const pt_model& mo = d.models[m];
+        if (mo.material < 0 || (uint32_t)mo.material >= d.n_materials) fail(PT_ERR_INVALID, "model %u: bad material index", m);
+        if (mo.kind == PT_MODEL_MESH && (uint64_t)mo.tri_first + mo.tri_count > d.n_triangles)
+            fail(PT_ERR_INVALID, "model %u: triangle range out of bounds", m);
+        if (mo.kind != PT_MODEL_MESH && mo.kind != PT_MODEL_SPHERE) fail(PT_ERR_INVALID, "model %u: bad kind", m);
+    }
+    for (uint32_t m = 0; m < d.n_materials; ++m) {
+        const pt_material& ma = d.materials[m];
+        const int32_t tx[6] = {ma.tex_albedo, ma.tex_emissive, ma.tex_opacity, ma.tex_metalness, ma.tex_roughness, ma.tex_normal};
+        const uint32_t ch[6] = {3, 3, 1, 1, 1, 3};
+        for (int k = 0; k < 6; ++k) {
+            if (tx[k] < 0) continue;
+            if ((uint32_t)tx[k] >= d.n_textures) fail(PT_ERR_INVALID, "material %u: texture index out of range", m);
+            const pt_texture& t = d.textures[tx[k]];
+            if (t.channels != ch[k]) fail(PT_ERR_INVALID, "material %u: texture %d has %u channels, expected %u", m, tx[k], t.channels, ch[k]);
+            if (t.width == 0 || t.height == 0 || t.offset + (uint64_t)t.width * t.height * t.channels > d.n_texel_bytes)
+                fail(PT_ERR_INVALID, "texture %d: bad extent", tx[k]);
+        }
+    }
+
+    // ---- KD-tree
+    pth_kdtree kd;
+    if (pth_kd_build(&d, &kd) != PT_OK) fail(PT_ERR_INVALID, "KD build failed: %s", pth_last_error());
+    std::unique_ptr<pth_kdtree, void (*)(pth_kdtree*)> kd_guard(&kd, pth_kd_free);
+    if (kd.depth >= PT_KD_STACK) fail(PT_ERR_UNSUPPORTED, "KD-tree depth %u exceeds the traversal stack", kd.depth);
+    auto t_up = std::chrono::steady_clock::now();
+
+    // ---- per-primitive arrays
+    uint64_t n_prims = pth_prim_count(&d);
+    std::vector<float4> attr(n_prims * 4), pos(n_prims * 3);
+    std::vector<pt_material> model_mat(d.n_models);
+    bool translucent = false;
+    uint64_t prim = 0;
+    for (uint32_t m = 0; m < d.n_models; ++m) {
+        const pt_model& mo = d.models[m];
+        model_mat[m] = d.materials[mo.material];
+        if (model_mat[m].opacity != 1.0f || model_mat[m].tex_opacity >= 0) translucent = true;
+        float mbits;
+        memcpy(&mbits, &m, 4);
+        if (mo.kind == PT_MODEL_MESH) {
+            for (uint32_t t = 0; t < mo.tri_count; ++t, ++prim) {
+                const float* v = d.triangles + (size_t)(mo.tri_first + t) * 24;
+                const float *a = v, *b = v + 8, *c = v + 16;
+                attr[prim * 4 + 0] = make_float4(a[3], a[4], a[5], a[6]);
+                attr[prim * 4 + 1] = make_float4(b[3], b[4], b[5], a[7]);
+                attr[prim * 4 + 2] = make_float4(c[3], c[4], c[5], b[6]);
+                attr[prim * 4 + 3] = make_float4(b[7], c[6], c[7], mbits);
+                float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+                float e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+                uint32_t pid = (uint32_t)prim;
+                float pbits;
+                memcpy(&pbits, &pid, 4);
+                pos[prim * 3 + 0] = make_float4(a[0], a[1], a[2], pbits);
+                pos[prim * 3 + 1] = make_float4(e1[0], e1[1], e1[2], e2[0]);
+                pos[prim * 3 + 2] = make_float4(e2[1], e2[2], 0.f, 0.f);
+            }
+        } else {
+            attr[prim * 4 + 0] = make_float4(mo.center[0], mo.center[1], mo.center[2], mo.radius);
+            attr[prim * 4 + 1] = attr[prim * 4 + 2] = make_float4(0, 0, 0, 0);
+            attr[prim * 4 + 3] = make_float4(0, 0, 0, mbits);
+            uint32_t pid = (uint32_t)prim | PT_PRIM_SPHERE;
+            float pbits;
+            memcpy(&pbits, &pid, 4);
+            pos[prim * 3 + 0] = make_float4(mo.center[0], mo.center[1], mo.center[2], pbits);
+            pos[prim * 3 + 1] = make_float4(mo.radius, 0, 0, 0);
+            pos[prim * 3 + 2] = make_float4(0, 0, 0, 0);
+            ++prim;
+        }
+    }
+    // leaf records in leaf-reference order
+    std::vector<float4> leaf(kd.n_refs * 3);
+    for (uint64_t r = 0; r < kd.n_refs; ++r) {
+        uint32_t p = kd.refs[r];
+        leaf[r * 3 + 0] = pos[(size_t)p * 3 + 0];
+        leaf[r * 3 + 1] = pos[(size_t)p * 3 + 1];
+        leaf[r * 3 + 2] = pos[(size_t)p * 3 + 2];
+    }
+    // sRGB -> linear table: (c as f32 / 255.0).powf(2.2) with the host libm (material.rs:137-141)
+    float lut[256];
+    for (int c = 0; c < 256; ++c) lut[c] = powf((float)c / 255.0f, 2.2f);
+    std::vector<DevLight> lights(d.n_lights);
+    for (uint32_t i = 0; i < d.n_lights; ++i) {
+        lights[i].kind = d.lights[i].kind;
+        memcpy(lights[i].vec, d.lights[i].vec, 12);
+        memcpy(lights[i].color, d.lights[i].color, 12);
+        lights[i]._pad = 0.f;
+    }
+
+    DevScene& D = s.dev;
+    D.kd_nodes = (const uint2*)s.upload(kd.nodes, kd.n_nodes);
+    D.leaf_prims = s.upload(leaf.data(), leaf.size());
+    D.prim_attr = s.upload(attr.data(), attr.size());
+    D.prim_pos = s.upload(pos.data(), pos.size());
+    D.materials = s.upload(model_mat.data(), model_mat.size());
+    D.textures = s.upload(d.textures, d.n_textures);
+    D.texels = s.upload(d.texels, d.n_texel_bytes);
+    D.srgb_lut = s.upload(lut, 256);
+    D.lights = s.upload(lights.data(), lights.size());
+    D.n_lights = d.n_lights;
+    D.n_prims = (uint32_t)n_prims;
+    D.n_nodes = (uint32_t)kd.n_nodes;
+    D.has_translucent = translucent ? 1u : 0u;
+    for (int a = 0; a < 3; ++a) {
+        float pad = 1e-4f * std::max(fabsf(kd.bounds_min[a]), fabsf(kd.bounds_max[a])) + 1e-5f;
+        D.bounds_min[a] = kd.bounds_min[a] - pad;
+        D.bounds_max[a] = kd.bounds_max[a] + pad;
+    }
+    const float* M = d.camera.transform;
+    memcpy(D.cam_c0, M, 12);
+    memcpy(D.cam_c1, M + 4, 12);
+    memcpy(D.cam_c2, M + 8, 12);
+    memcpy(D.cam_c3, M + 12, 12);
+    D.tan_half_fov = tanf(d.camera.fov / 2.f);  // Rad::tan(fov / 2.) (mod.rs:116,120)
+    memcpy(D.background, d.background, 12);
+
+    s.info.n_prims = n_prims;
+    s.info.n_kd_nodes = kd.n_nodes;
+    s.info.n_kd_leaves = kd.n_leaves;
+    s.info.n_leaf_refs = kd.n_refs;
+    s.info.kd_depth = kd.depth;
+    s.info.has_translucent = translucent;
+    s.info.kd_build_seconds = (float)kd.build_seconds;
+    s.info.upload_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_up).count();
+}
+
+hipEvent_t get_event(const pt_scene& s, size_t i) {
+    while (s.events.size() <= i) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        s.events.push_back(e);
+    }
+    return s.events[i];
+}
+
+void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_in, void* d_rgb8, void* d_accum,
+                   hipStream_t stream) {
+    pt_opts o;
+    normalise_opts(p, opts_in, o);
+    if (p.samples == 0) fail(PT_ERR_INVALID, "profile.samples must be > 0");
+    if (p.brdf != PT_BRDF_COOK_TORRANCE) fail(PT_ERR_INVALID, "unknown brdf %d", p.brdf);
+    if (p.tonemap < 0 || p.tonemap > 2) fail(PT_ERR_INVALID, "unknown tonemap %d", p.tonemap);
+    HIP_CHECK(hipSetDevice(s.device));
+    TileMap tm = make_tile_map(p, o, o.shard_rank);
+    if (tm.n_local == 0) return;
+
+    // tile offset table (cached per configuration: no host sync in steady state)
+    const uint32_t* d_tiles = nullptr;
+    if (o.shard_count > 1) {
+        auto key = std::make_tuple(p.width, p.height, o.shard_rank, o.shard_count, o.tile_w, o.tile_h);
+        if (key != s.tile_key || !s.tile_table.p) {
+            s.tile_table.ensure(tm.offsets.size() * 4);
+            HIP_CHECK(hipMemcpy(s.tile_table.p, tm.offsets.data(), tm.offsets.size() * 4, hipMemcpyHostToDevice));
+            s.tile_key = key;
+        }
+        d_tiles = (const uint32_t*)s.tile_table.p;
+    }
+    float* accum = (float*)d_accum;
+    if (!accum) {
+        s.accum_scratch.ensure(tm.n_local * 12);
+        accum = (float*)s.accum_scratch.p;
+    }
+    const bool timing = o.flags & PT_FLAG_TIMING, counting = o.flags & PT_FLAG_COUNTERS;
+    if (counting) {
+        s.counter_buf.ensure(sizeof(DevCounters));
+        HIP_CHECK(hipMemsetAsync(s.counter_buf.p, 0, sizeof(DevCounters), stream));
+    }
+
+    RenderParams P{};
+    P.width = p.width;
+    P.height = p.height;
+    P.samples = p.samples;
+    P.bounces = p.bounces;
+    P.tonemap = p.tonemap;
+    P.shard_rank = o.shard_rank;
+    P.shard_count = o.shard_count;
+    P.tile_w = o.tile_w;
+    P.tile_h = o.tile_h;
+    P.tiles_x = tm.tiles_x;
+    P.tiles_y = tm.tiles_y;
+    P.n_local = (uint32_t)tm.n_local;
+
+    uint32_t batch = o.sample_batch ? o.sample_batch : p.samples;
+    uint32_t blocks = tm.n_local_tiles * (o.tile_w * o.tile_h / 256u);
+    size_t ev = 0;
+    uint32_t launches = 0;
+    for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
+        P.sample_begin = s0;
+        P.sample_end = std::min(p.samples, s0 + batch);
+        if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+        if (counting)
+            hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum,
+                               (DevCounters*)s.counter_buf.p);
+        else
+            hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum,
+                               (DevCounters*)nullptr);
+        HIP_CHECK(hipGetLastError());
+        if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+        ++launches;
+        if (o.progress) {
+            HIP_CHECK(hipStreamSynchronize(stream));
+            o.progress(P.sample_end, p.samples, o.progress_user);
+        }
+    }
+    if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+    if (d_rgb8) {
+        hipLaunchKernelGGL(k_postprocess, dim3(((uint32_t)tm.n_local + 255u) / 256u), dim3(256), 0, stream, accum,
+                           (uint8_t*)d_rgb8, (uint32_t)tm.n_local, p.samples, p.tonemap);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+
+    if (timing || counting) HIP_CHECK(hipStreamSynchronize(stream));
+    if (timing) {
+        pt_timing t{};
+        t.launches = launches;
+        for (uint32_t l = 0; l < launches; ++l) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, s.events[2 * l], s.events[2 * l + 1]));
+            t.integrate_ms += ms;
+        }
+        HIP_CHECK(hipEventElapsedTime(&t.postprocess_ms, s.events[2 * launches], s.events[2 * launches + 1]));
+        HIP_CHECK(hipEventElapsedTime(&t.total_ms, s.events[0], s.events[2 * launches + 1]));
+        s.timing = t;
+    }
+    if (counting) {
+        DevCounters c;
+        HIP_CHECK(hipMemcpy(&c, s.counter_buf.p, sizeof c, hipMemcpyDeviceToHost));
+        s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
+                                 c.rng_draws, c.restarts};
+    }
+}
+
+template <class T>
+struct Staged {  // host -> device copy of a test-hook input, freed on scope exit
+    T* d = nullptr;
+    Staged(const T* host, size_t count) {
+        HIP_CHECK(hipMalloc((void**)&d, std::max<size_t>(16, count * sizeof(T))));
+        if (host && count) HIP_CHECK(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    }
+    ~Staged() {
+        if (d) (void)hipFree(d);
+    }
+    void fetch(T* host, size_t count) { HIP_CHECK(hipMemcpy(host, d, count * sizeof(T), hipMemcpyDeviceToHost)); }
+};
+
+}  // namespace
+
+// ==================================================================== C ABI
+extern "C" {
+
+const char* pt_last_error(void) { return g_err.c_str(); }
+const char* pt_version(void) { return "path-tracer_amd 0.1 (gfx950)"; }
+
+int pt_scene_create(const pt_scene_desc* desc, int device, pt_scene** out) {
+    return guarded([&] {
+        if (!desc || !out) fail(PT_ERR_INVALID, "pt_scene_create: null argument");
+        auto s = std::make_unique<pt_scene>();
+        scene_create(*desc, device, *s);
+        *out = s.release();
+    });
+}
+
+void pt_scene_destroy(pt_scene* scene) { delete scene; }
+
+uint64_t pt_local_pixel_count(const pt_profile* profile, const pt_opts* opts) {
+    uint64_t n = 0;
+    guarded([&] {
+        if (!profile) fail(PT_ERR_INVALID, "pt_local_pixel_count: null profile");
+        pt_opts o;
+        normalise_opts(*profile, opts, o);
+        n = make_tile_map(*profile, o, o.shard_rank).n_local;
+    });
+    return n;
+}
+
+int pt_local_pixel_map(const pt_profile* profile, const pt_opts* opts, uint32_t* out) {
+    return guarded([&] {
+        if (!profile || !out) fail(PT_ERR_INVALID, "pt_local_pixel_map: null argument");
+        pt_opts o;
+        normalise_opts(*profile, opts, o);
+        const pt_profile& p = *profile;
+        if (o.shard_count <= 1) {
+            for (uint64_t i = 0; i < (uint64_t)p.width * p.height; ++i) out[i] = (uint32_t)i;
+            return;
+        }
+        TileMap tm = make_tile_map(p, o, o.shard_rank);
+        for (uint32_t lt = 0; lt < tm.n_local_tiles; ++lt) {
+            uint32_t k = o.shard_rank + lt * o.shard_count;
+            uint32_t tx = k % tm.tiles_x, ty = k / tm.tiles_x;
+            uint32_t cw = std::min(o.tile_w, p.width - tx * o.tile_w), ch = std::min(o.tile_h, p.height - ty * o.tile_h);
+            for (uint32_t y = 0; y < ch; ++y)
+                for (uint32_t x = 0; x < cw; ++x)
+                    out[tm.offsets[lt] + y * cw + x] = (tx * o.tile_w + x) + (ty * o.tile_h + y) * p.width;
+        }
+    });
+}
+
+int pt_render_device(const pt_scene* scene, const pt_profile* profile, const pt_opts* opts, void* d_rgb8,
+                     void* d_accum, void* hip_stream) {
+    return guarded([&] {
+        if (!scene || !profile) fail(PT_ERR_INVALID, "pt_render_device: null argument");
+        render_device(*scene, *profile, opts, d_rgb8, d_accum, (hipStream_t)hip_stream);
+    });
+}
+
+int pt_render(const pt_scene* scene, const pt_profile* profile, const pt_opts* opts, uint8_t* rgb8, float* accum) {
+    return guarded([&] {
+        if (!scene || !profile) fail(PT_ERR_INVALID, "pt_render: null argument");
+        HIP_CHECK(hipSetDevice(scene->device));
+        pt_opts o;
+        normalise_opts(*profile, opts, o);
+        uint64_t n = make_tile_map(*profile, o, o.shard_rank).n_local;
+        Staged<uint8_t> d_rgb(nullptr, n * 3);
+        Staged<float> d_acc(nullptr, n * 3);
+        render_device(*scene, *profile, opts, d_rgb.d, d_acc.d, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        if (rgb8) d_rgb.fetch(rgb8, n * 3);
+        if (accum) d_acc.fetch(accum, n * 3);
+    });
+}
+
+int pt_assemble_tiles(const pt_profile* profile, uint32_t shard_count, uint32_t tile_w, uint32_t tile_h,
+                      uint64_t slice_pixels, uint32_t elem_bytes, const void* d_gathered, void* d_image,
+                      void* hip_stream) {
+    return guarded([&] {
+        if (!profile || !d_gathered || !d_image) fail(PT_ERR_INVALID, "pt_assemble_tiles: null argument");
+        pt_opts o{};
+        o.shard_count = shard_count;
+        o.tile_w = tile_w;
+        o.tile_h = tile_h;
+        pt_opts on;
+        normalise_opts(*profile, &o, on);
+        if (on.shard_count <= 1) {
+            HIP_CHECK(hipMemcpyAsync(d_image, d_gathered, (size_t)profile->width * profile->height * elem_bytes,
+                                     hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+            return;
+        }
+        uint32_t max_local = 0;
+        std::vector<TileMap> maps;
+        for (uint32_t r = 0; r < on.shard_count; ++r) {
+            maps.push_back(make_tile_map(*profile, on, r));
+            max_local = std::max(max_local, maps.back().n_local_tiles);
+            if (maps.back().n_local > slice_pixels) fail(PT_ERR_INVALID, "slice_pixels too small for rank %u", r);
+        }
+        std::vector<uint32_t> table((size_t)on.shard_count * std::max(1u, max_local), 0);
+        for (uint32_t r = 0; r < on.shard_count; ++r)
+            for (uint32_t lt = 0; lt < maps[r].n_local_tiles; ++lt) table[(size_t)r * max_local + lt] = maps[r].offsets[lt];
+        Staged<uint32_t> d_table(table.data(), table.size());
+        uint32_t npix = profile->width * profile->height;
+        hipLaunchKernelGGL(k_assemble, dim3((npix + 255u) / 256u), dim3(256), 0, (hipStream_t)hip_stream,
+                           (const uint8_t*)d_gathered, (uint8_t*)d_image, d_table.d, max_local, profile->width,
+                           profile->height, on.shard_count, on.tile_w, on.tile_h, maps[0].tiles_x, slice_pixels,
+                           elem_bytes);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)hip_stream));  // d_table is freed on return
+    });
+}
+
+int pt_get_timing(const pt_scene* scene, pt_timing* out) {
+    if (!scene || !out) return PT_ERR_INVALID;
+    *out = scene->timing;
+    return PT_OK;
+}
+int pt_get_counters(const pt_scene* scene, pt_counters* out) {
+    if (!scene || !out) return PT_ERR_INVALID;
+    *out = scene->counters;
+    return PT_OK;
+}
+int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out) {
+    if (!scene || !out) return PT_ERR_INVALID;
+    *out = scene->info;
+    return PT_OK;
+}
+
+int pt_trace_rays(const pt_scene* scene, const float* rays, uint64_t n, pt_hit* out) {
+    return guarded([&] {
+        if (!scene || !rays || !out) fail(PT_ERR_INVALID, "pt_trace_rays: null argument");
+        if (n == 0) return;
+        HIP_CHECK(hipSetDevice(scene->device));
+        Staged<float> d_rays(rays, n * 6);
+        Staged<pt_hit> d_out(nullptr, n);
+        hipLaunchKernelGGL(k_trace, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, scene->dev, d_rays.d, n, d_out.d);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        d_out.fetch(out, n);
+    });
+}
+
+int pt_trace_rays_all(const pt_scene* scene, const float* rays, uint64_t n, uint32_t max_hits, pt_hit* out,
+                      uint32_t* counts) {
+    return guarded([&] {
+        if (!scene || !rays || !out || !counts || !max_hits) fail(PT_ERR_INVALID, "pt_trace_rays_all: bad argument");
+        if (n == 0) return;
+        HIP_CHECK(hipSetDevice(scene->device));
+        Staged<float> d_rays(rays, n * 6);
+        Staged<pt_hit> d_out(nullptr, n * max_hits);
+        Staged<uint32_t> d_cnt(nullptr, n);
+        hipLaunchKernelGGL(k_trace_all, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, scene->dev, d_rays.d, n,
+                           max_hits, d_out.d, d_cnt.d);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        d_out.fetch(out, n * max_hits);
+        d_cnt.fetch(counts, n);
+    });
+}
+
+int pt_intersect_triangles(int device, const float* rays, const float* tris, uint64_t n, pt_hit* out) {
+    return guarded([&] {
+        if (!rays || !tris || !out) fail(PT_ERR_INVALID, "pt_intersect_triangles: null argument");
+        if (n == 0) return;
+        select_device(device);
+        Staged<float> d_rays(rays, n * 6), d_tris(tris, n * 9);
+        Staged<pt_hit> d_out(nullptr, n);
+        hipLaunchKernelGGL(k_isect, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, d_rays.d, d_tris.d, n, d_out.d);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        d_out.fetch(out, n);
+    });
+}
+
+int pt_rng_words(int device, const uint64_t* seeds, uint64_t n_seeds, uint32_t n_words, uint32_t* out) {
+    return guarded([&] {
+        if (!seeds || !out) fail(PT_ERR_INVALID, "pt_rng_words: null argument");
+        if (n_seeds == 0 || n_words == 0) return;
+        select_device(device);
+        Staged<uint64_t> d_seeds(seeds, n_seeds);
+        Staged<uint32_t> d_out(nullptr, n_seeds * n_words);
+        hipLaunchKernelGGL(k_rng, dim3((uint32_t)((n_seeds + 255) / 256)), dim3(256), 0, 0, d_seeds.d, n_seeds, n_words, d_out.d);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        d_out.fetch(out, n_seeds * n_words);
+    });
+}
+
+int pt_eval_math(int device, int fn, const float* x, uint64_t n, float* out) {
+    return guarded([&] {
+        if (!x || !out) fail(PT_ERR_INVALID, "pt_eval_math: null argument");
+        if (fn < 0 || fn > 3) fail(PT_ERR_INVALID, "pt_eval_math: unknown function %d", fn);
+        if (n == 0) return;
+        select_device(device);
+        Staged<float> d_x(x, n), d_out(nullptr, n);
+        hipLaunchKernelGGL(k_math, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, fn, d_x.d, n, d_out.d);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        d_out.fetch(out, n);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,616 @@
+// Device integrator: KD-tree ray casting, Möller–Trumbore, material fetch,
+// Cook–Torrance, bounce loop.  One independent transcription of the
+// reference's hot path for gfx950 (the CPU oracle under oracle/ is a second,
+// separate one used only by the tests).
+//
+// Reference map (all under /root/reference/src):
+//   kd_traverse / next_hit      renderer/utils.rs:11-21 (ray_cast: all hits sorted by
+//                               distance; here: iterate "next hit after (dist, order)")
+//   isect_triangle              scene/internal/triangle.rs:37-82
+//   isect_sphere                scene/internal/model.rs:26-64
+//   make_surface                renderer/hit.rs:100-137, 55-82
+//   material_sample             renderer/material_sample.rs:20-40, scene/internal/material.rs:115-214
+//   CookTorrance ct_*           renderer/brdf/cook_torrance.rs:10-183, brdf/mod.rs:35-48, utils.rs:34-36
+//   light_radiance              renderer/mod.rs:281-333
+//   render_path                 renderer/mod.rs:172-278, utils.rs:23-31
+//   primary_ray                 renderer/mod.rs:107-124, scene/internal/camera.rs:36-48
+//   post_process                renderer/mod.rs:335-353, renderer/tonemap.rs:15-54
+#pragma once
+#include "pt_device.h"
+#include "pt_math.h"
+#include "pt_rng.h"
+
+struct LocalCtr {
+    uint32_t segments, shadow_rays, nodes, tris, shaded, restarts;
+};
+
+// One entry of the reference's sorted hit list.
+struct RawHit {
+    float key;       // Hit::get_dist(): the sort key of ray_cast (utils.rs:19)
+    uint32_t ord;    // tie order: primitive id * 2 (+1 for a sphere's exit hit)
+    uint32_t pid;    // primitive id | PT_PRIM_SPHERE
+    float u, v;      // barycentrics; spheres: u = ray parameter t of the hit
+    uint32_t flags;  // bit0 backface, bit1 sphere, bit2 sphere exit
+};
+
+// Relative / absolute slack of the front-to-back early exit (kd_build.cpp, robustness rules).
+#define PT_EXIT_REL 1.00001f
+#define PT_EXIT_ABS 1e-6f
+
+// ---------------------------------------------------------------------------
+// KD-tree traversal (front to back).  `leaf(first_ref, n_refs)` tests the
+// primitives of one leaf and returns true to stop the traversal; `limit` is
+// the largest hit key still of interest (the closest hit so far).  A node
+// whose entry parameter, scaled to key units, lies beyond `limit` ends the
+// walk.  The stack holds (far child, its exit parameter); the entry parameter
+// of a popped node is the exit parameter of the segment just finished.
+// ---------------------------------------------------------------------------
+template <bool COUNT, class LeafFn>
+PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_scale, float& limit,
+                      LocalCtr& lc, LeafFn&& leaf) {
+    const float oa[3] = {o.x, o.y, o.z};
+    const float da[3] = {d.x, d.y, d.z};
+    const float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    // clip against the (padded) scene bounds
+    float tmin = t_start, tmax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float tn = (S.bounds_min[a] - oa[a]) * inv[a];
+        float tf = (S.bounds_max[a] - oa[a]) * inv[a];
+        if (tn > tf) {
+            float tmp = tn;
+            tn = tf;
+            tf = tmp;
+        }
+        tmin = tn > tmin ? tn : tmin;   // NaN (0 * inf) never narrows the interval
+        tmax = tf < tmax ? tf : tmax;
+    }
+    if (tmin > tmax) return;
+
+    uint32_t st_node[PT_KD_STACK];
+    float st_tmax[PT_KD_STACK];
+    int sp = 0;
+    uint32_t node = 0;
+    while (true) {
+        uint2 nd = S.kd_nodes[node];
+        if (COUNT) lc.nodes++;
+        uint32_t axis = nd.y & 3u;
+        if (axis != 3u) {
+            float split = __uint_as_float(nd.x);
+            float oax = axis == 0 ? oa[0] : (axis == 1 ? oa[1] : oa[2]);
+            float dax = axis == 0 ? da[0] : (axis == 1 ? da[1] : da[2]);
+            float iax = axis == 0 ? inv[0] : (axis == 1 ? inv[1] : inv[2]);
+            float tplane = (split - oax) * iax;
+            bool below_first = (oax < split) || (oax == split && dax <= 0.f);
+            uint32_t below = node + 1, above = nd.y >> 2;
+            uint32_t first = below_first ? below : above;
+            uint32_t second = below_first ? above : below;
+            if (tplane > tmax || tplane <= 0.f) {
+                node = first;
+            } else if (tplane < tmin) {
+                node = second;
+            } else {  // also taken when tplane is NaN: visit both (conservative)
+                st_node[sp] = second;
+                st_tmax[sp] = tmax;
+                ++sp;
+                node = first;
+                tmax = tplane;
+            }
+            continue;
+        }
+        uint32_t n_refs = nd.y >> 2;
+        if (n_refs && leaf(nd.x, n_refs)) return;
+        // next segment
+        while (true) {
+            if (sp == 0) return;
+            --sp;
+            tmin = tmax;
+            node = st_node[sp];
+            tmax = st_tmax[sp];
+            // everything from here on starts at tmin: stop when that is beyond the best hit
+            if (tmin * key_scale > limit * PT_EXIT_REL + PT_EXIT_ABS) return;
+            break;
+        }
+    }
+}
+
+// Triangle::intersect on a leaf record (v0, e1, e2).  Returns true and fills
+// (dist, u, v, backface) on a hit.
+PT_D bool isect_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& dist, float& u, float& v, bool& backface) {
+    f3 pvec = cross3(d, e2);
+    float det = dot3(e1, pvec);
+    if (fabsf(det) < 0.000001f) return false;
+    float invdet = 1.0f / det;
+    f3 tvec = o - v0;
+    u = dot3(tvec, pvec) * invdet;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    f3 qvec = cross3(tvec, e1);
+    v = dot3(d, qvec) * invdet;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    dist = dot3(e2, qvec) * invdet;
+    // `dist < 1e-6` rejects; a NaN distance panics the reference's sort (utils.rs:19):
+    // it is rejected here.
+    if (!(dist >= 0.000001f)) return false;
+    backface = det < 0.0f;
+    return true;
+}
+
+// Model::intersect for spheres: returns the number of hits (0..2); t[] are the
+// ray parameters, key[] = |hit_point - origin| in the reference's order (entry first).
+PT_D int isect_sphere(f3 o, f3 d, f3 center, float radius, float t[2], float key[2], bool exit_hit[2]) {
+    f3 rc = o - center;
+    float a = dot3(d, d);
+    float b = 2.0f * dot3(rc, d);
+    float c = dot3(rc, rc) - radius * radius;
+    float disc = b * b - 4.0f * a * c;
+    if (disc < 0.0f) return 0;
+    float t1 = (-b - sqrtf(disc)) / (2.0f * a);
+    float t2 = (-b + sqrtf(disc)) / (2.0f * a);
+    if (!(t1 <= t2)) return 0;  // assert!(t1 <= t2) in the reference
+    if (t2 < 0.0f) return 0;
+    f3 p2 = o + d * t2;
+    float k2 = mag3(p2 - o);
+    if (t1 < 0.0f) {
+        t[0] = t2;
+        key[0] = k2;
+        exit_hit[0] = true;
+        return 1;
+    }
+    f3 p1 = o + d * t1;
+    t[0] = t1;
+    key[0] = mag3(p1 - o);
+    exit_hit[0] = false;
+    t[1] = t2;
+    key[1] = k2;
+    exit_hit[1] = true;
+    return 2;
+}
+
+PT_D bool key_less(float ka, uint32_t oa, float kb, uint32_t ob) { return ka < kb || (ka == kb && oa < ob); }
+
+// The entry of ray_cast()'s sorted list that follows (t_prev, ord_prev); the
+// first entry for t_prev = -inf.  Returns false when the list is exhausted.
+template <bool COUNT>
+PT_D bool next_hit(const DevScene& S, f3 o, f3 d, float t_prev, uint32_t ord_prev, RawHit& best, LocalCtr& lc) {
+    best.key = INFINITY;
+    best.ord = 0xffffffffu;
+    best.pid = 0xffffffffu;
+    float dlen = mag3(d);
+    float key_scale = dlen < 1.0f ? dlen : 1.0f;              // key >= t * min(1, |d|)
+    float t_start = t_prev > 0.f ? t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f) * 0.99999f - 1e-6f : 0.f;
+    if (!(t_start > 0.f)) t_start = 0.f;
+    float limit = INFINITY;
+    kd_traverse<COUNT>(S, o, d, t_start, key_scale, limit, lc, [&](uint32_t first, uint32_t n) {
+        const float4* lp = S.leaf_prims + (size_t)first * 3;
+        for (uint32_t i = 0; i < n; ++i) {
+            float4 q0 = lp[3 * i], q1 = lp[3 * i + 1], q2 = lp[3 * i + 2];
+            uint32_t pid = __float_as_uint(q0.w);
+            if (COUNT) lc.tris++;
+            if (!(pid & PT_PRIM_SPHERE)) {
+                float dist, u, v;
+                bool bf;
+                if (!isect_triangle(o, d, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), dist,
+                                    u, v, bf))
+                    continue;
+                uint32_t ord = pid * 2u;
+                if (key_less(t_prev, ord_prev, dist, ord) && key_less(dist, ord, best.key, best.ord)) {
+                    best.key = dist;
+                    best.ord = ord;
+                    best.pid = pid;
+                    best.u = u;
+                    best.v = v;
+                    best.flags = bf ? 1u : 0u;
+                    limit = dist;
+                }
+            } else {
+                float t[2], key[2];
+                bool ex[2];
+                int nh = isect_sphere(o, d, mk3(q0.x, q0.y, q0.z), q1.x, t, key, ex);
+                for (int k = 0; k < nh; ++k) {
+                    uint32_t ord = (pid & ~PT_PRIM_SPHERE) * 2u + (ex[k] ? 1u : 0u);
+                    if (key[k] == key[k] && key_less(t_prev, ord_prev, key[k], ord) &&
+                        key_less(key[k], ord, best.key, best.ord)) {
+                        best.key = key[k];
+                        best.ord = ord;
+                        best.pid = pid;
+                        best.u = t[k];
+                        best.v = 0.f;
+                        best.flags = 2u | (ex[k] ? 4u : 0u);
+                        limit = key[k];
+                    }
+                }
+            }
+        }
+        return false;
+    });
+    return best.pid != 0xffffffffu;
+}
+
+// ---------------------------------------------------------------------------
+// Surface record = the reference's Hit (renderer/hit.rs:5-37) + model index.
+// ---------------------------------------------------------------------------
+struct Surface {
+    f3 pos;
+    f3 normal;     // Hit::get_geometric_normal(): interpolated, NOT normalised (triangles)
+    f3 tangent;    // only valid when the material has a normal map
+    f2 uv;
+    uint32_t model;
+    bool sphere;
+    bool backface;
+};
+
+PT_D void make_surface(const DevScene& S, f3 o, f3 d, const RawHit& h, Surface& s) {
+    uint32_t prim = h.pid & ~PT_PRIM_SPHERE;
+    const float4* at = S.prim_attr + (size_t)prim * 4;
+    float4 a3 = at[3];
+    s.model = __float_as_uint(a3.w);
+    if (h.flags & 2u) {  // Model::intersect sphere arm (model.rs:40-63)
+        float4 a0 = at[0];
+        f3 center = mk3(a0.x, a0.y, a0.z);
+        f3 hp = o + d * h.u;
+        f3 n = normalize3(hp - center);
+        s.pos = hp;
+        s.normal = (h.flags & 4u) ? -n : n;
+        s.sphere = true;
+        s.backface = false;
+        s.uv = {0.f, 0.f};
+        s.tangent = mk3(0.f, 0.f, 0.f);
+        return;
+    }
+    float4 a0 = at[0], a1 = at[1], a2 = at[2];
+    float u = h.u, v = h.v;
+    // Hit::new_triangle (hit.rs:100-137)
+    f3 n0 = mk3(a0.x, a0.y, a0.z), n1 = mk3(a1.x, a1.y, a1.z), n2 = mk3(a2.x, a2.y, a2.z);
+    f2 uv0 = {a0.w, a1.w}, uv1 = {a2.w, a3.x}, uv2 = {a3.y, a3.z};
+    s.normal = (1.0f - u - v) * n0 + u * n1 + v * n2;
+    s.uv = uv0 + u * (uv1 - uv0) + v * (uv2 - uv0);
+    s.pos = o + d * h.key;  // ray.origin + ray.direction * dist (triangle.rs:77)
+    s.sphere = false;
+    s.backface = (h.flags & 1u) != 0;
+    s.tangent = mk3(0.f, 0.f, 0.f);
+    if (S.materials[s.model].tex_normal >= 0) {
+        const float4* pp = S.prim_pos + (size_t)prim * 3;
+        float4 q1 = pp[1], q2 = pp[2];
+        f3 edge1 = mk3(q1.x, q1.y, q1.z), edge2 = mk3(q1.w, q2.x, q2.y);
+        f2 duv1 = uv1 - uv0, duv2 = uv2 - uv0;
+        float f = 1.0f / (duv1.x * duv2.y - duv2.x * duv1.y);
+        s.tangent = normalize3(mk3(f * (duv2.y * edge1.x - duv1.y * edge2.x), f * (duv2.y * edge1.y - duv1.y * edge2.y),
+                                   f * (duv2.y * edge1.z - duv1.y * edge2.z)));
+    }
+}
+
+// Material::get_pixel (material.rs:115-130): nearest texel, wrap, row 0 = top.
+PT_D const uint8_t* texel(const DevScene& S, int32_t tex, f2 uv) {
+    pt_texture t = S.textures[tex];
+    uint32_t px = wrap_texel(uv.x * (float)t.width, t.width);
+    uint32_t py = wrap_texel(uv.y * (float)t.height, t.height);
+    return S.texels + t.offset + ((size_t)py * t.width + px) * t.channels;
+}
+
+PT_D float luma_channel(const DevScene& S, int32_t tex, float factor, f2 uv) {
+    if (tex >= 0) return (float)texel(S, tex, uv)[0] / 255.f * factor;
+    return factor;
+}
+
+struct MatSample {  // renderer/material_sample.rs:6-18 (ior is carried but unused by the BRDF)
+    float metalness, roughness, opacity;
+    f3 albedo, emissive;
+};
+
+// Hit::get_material_sample(model): `kind_sphere`/`uv` come from the hit, the
+// material from the model (mod.rs:324 mixes the two on purpose).
+PT_D float material_opacity(const DevScene& S, uint32_t model, bool kind_sphere, f2 uv) {
+    const pt_material& m = S.materials[model];
+    if (kind_sphere) return m.opacity;
+    return luma_channel(S, m.tex_opacity, m.opacity, uv);
+}
+
+PT_D void material_sample(const DevScene& S, uint32_t model, bool kind_sphere, f2 uv, MatSample& r) {
+    const pt_material& m = S.materials[model];
+    f3 albedo = ld3(m.albedo), emissive = ld3(m.emissive);
+    if (kind_sphere) {  // MaterialSample::simple
+        r.metalness = m.metalness;
+        r.roughness = max_rs(m.roughness, 0.0001f);
+        r.albedo = albedo;
+        r.opacity = m.opacity;
+        r.emissive = emissive;
+        return;
+    }
+    r.metalness = luma_channel(S, m.tex_metalness, m.metalness, uv);
+    r.roughness = max_rs(luma_channel(S, m.tex_roughness, m.roughness, uv), 0.0001f);
+    if (m.tex_albedo >= 0) {
+        const uint8_t* p = texel(S, m.tex_albedo, uv);
+        // (c/255).powf(2.2): 256 possible values, tabulated by the host libm
+        r.albedo = mul_ew(mk3(S.srgb_lut[p[0]], S.srgb_lut[p[1]], S.srgb_lut[p[2]]), albedo);
+    } else {
+        r.albedo = albedo;
+    }
+    r.opacity = luma_channel(S, m.tex_opacity, m.opacity, uv);
+    if (m.tex_emissive >= 0) {
+        const uint8_t* p = texel(S, m.tex_emissive, uv);
+        r.emissive = mul_ew(mk3((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f), emissive);
+    } else {
+        r.emissive = emissive;
+    }
+}
+
+// Hit::get_normal (hit.rs:55-82)
+PT_D f3 shading_normal(const DevScene& S, const Surface& s) {
+    if (s.sphere) return s.normal;
+    const pt_material& m = S.materials[s.model];
+    f3 n = s.normal;
+    if (m.tex_normal >= 0) {
+        const uint8_t* p = texel(S, m.tex_normal, s.uv);
+        f3 nm = mk3((float)p[0] / 127.5f - 1.f, (float)p[1] / 127.5f - 1.f, (float)p[2] / 127.5f - 1.f);
+        f3 bitangent = cross3(s.normal, s.tangent);
+        n = normalize3(s.tangent * nm.x + bitangent * nm.y + s.normal * nm.z);
+    }
+    return s.backface ? -n : n;
+}
+
+// ---------------------------------------------------------------------------
+// Cook–Torrance (cook_torrance.rs)
+// ---------------------------------------------------------------------------
+struct Brdf {
+    float metalness, roughness;
+    f3 albedo, emissive, f0, wm;
+};
+
+PT_D void ct_init(Brdf& b, const MatSample& m) {
+    b.metalness = m.metalness;
+    b.roughness = m.roughness;
+    b.albedo = m.albedo;
+    b.emissive = m.emissive;
+    b.f0 = mk3(0.04f, 0.04f, 0.04f) * (1.f - m.metalness) + m.albedo * m.metalness;
+    b.wm = mk3(0.f, 0.f, 0.f);
+}
+PT_D f3 ct_fresnel(const Brdf& b, float cos_theta) {
+    return b.f0 + mk3(1.f - b.f0.x, 1.f - b.f0.y, 1.f - b.f0.z) * powi5(1.f - cos_theta);
+}
+PT_D float ct_g1(float ndv, float k) { return ndv / (ndv * (1.f - k) + k); }
+PT_D float ct_geometry(const Brdf& b, f3 n, f3 v, f3 l) {
+    float ndv = max_rs(dot3(n, v), 0.f);
+    float ndl = max_rs(dot3(n, l), 0.f);
+    float k = powi2(b.roughness + 1.f) / 8.f;
+    return ct_g1(ndv, k) * ct_g1(ndl, k);
+}
+PT_D float ct_distribution(const Brdf& b, f3 n, f3 h) {
+    float a = b.roughness * b.roughness;
+    float a2 = a * a;
+    float ndh = max_rs(dot3(n, h), 0.f);
+    float ndh2 = ndh * ndh;
+    float denom = ndh2 * (a2 - 1.f) + 1.f;
+    denom = PT_PI * denom * denom;
+    return a2 / denom;
+}
+PT_D f3 ct_diffuse(const Brdf& b, f3 ks, f3 n, f3 l) {
+    f3 kd = mk3(1.f - ks.x, 1.f - ks.y, 1.f - ks.z) * (1.f - b.metalness);
+    f3 diffuse = mul_ew(kd, b.albedo) / PT_PI;
+    return diffuse * max_rs(dot3(n, l), 0.f);
+}
+PT_D f3 ct_eval_direct(const Brdf& b, f3 n, f3 view, f3 light) {
+    f3 h = normalize3(view + light);
+    float dterm = ct_distribution(b, n, h);
+    f3 f = ct_fresnel(b, max_rs(dot3(h, view), 0.f));
+    float g = ct_geometry(b, n, view, light);
+    f3 spec = (dterm * f * g) / max_rs(4.f * max_rs(dot3(n, view), 0.f) * max_rs(dot3(n, light), 0.f), 0.0001f);
+    spec = spec * max_rs(dot3(n, light), 0.f);
+    f3 diff = ct_diffuse(b, f, n, light);
+    return diff + spec + b.emissive;
+}
+PT_D f3 ct_eval_indirect(const Brdf& b, f3 n, f3 view, f3 light) {
+    f3 h = normalize3(view + light);
+    f3 f = ct_fresnel(b, max_rs(dot3(h, view), 0.f));
+    float g = ct_geometry(b, n, view, light);
+    f3 spec = mk3(0.f, 0.f, 0.f);
+    if (dot3(n, light) > 0.f) {
+        float wn = fabsf(dot3(view, b.wm));
+        float wd = fabsf(dot3(view, n)) * fabsf(dot3(b.wm, n));
+        spec = f * g * (wn / wd);
+    }
+    return ct_diffuse(b, f, n, light) + spec;
+}
+PT_D f3 transform_to_world(f3 vec, f3 n) {
+    f3 nt;
+    if (fabsf(n.x) > fabsf(n.y)) nt = mk3(n.z, 0.f, -n.x) / sqrtf(n.x * n.x + n.z * n.z);
+    else nt = mk3(0.f, -n.z, n.y) / sqrtf(n.y * n.y + n.z * n.z);
+    f3 nb = cross3(n, nt);
+    return mk3(vec.x * nb.x + vec.y * n.x + vec.z * nt.x, vec.x * nb.y + vec.y * n.y + vec.z * nt.y,
+               vec.x * nb.z + vec.y * n.z + vec.z * nt.z);
+}
+PT_D f3 ct_sample(Brdf& b, f3 n, f3 v, float r1, float r2) {
+    float a = b.roughness * b.roughness;
+    float a2 = a * a;
+    float theta = pt_acosf(sqrtf((1.f - r1) / (r1 * (a2 - 1.f) + 1.f)));
+    float phi = 2.f * PT_PI * r2;
+    float st = pt_sinf(theta);
+    f3 m = normalize3(mk3(st * pt_cosf(phi), pt_cosf(theta), st * pt_sinf(phi)));
+    b.wm = normalize3(transform_to_world(m, n));
+    f3 dir = (2.f * max_rs(dot3(v, b.wm), 0.f)) * b.wm - v;  // reflection(): utils.rs:34-36
+    return normalize3(dir);
+}
+
+// ---------------------------------------------------------------------------
+// Direct light (get_light_info, mod.rs:281-333)
+// ---------------------------------------------------------------------------
+template <bool COUNT>
+PT_D void light_radiance(const DevScene& S, const DevLight& L, const Surface& hit, f3& radiance, f3& direction,
+                         LocalCtr& lc) {
+    const bool point = L.kind == PT_LIGHT_POINT;
+    f3 color = ld3(L.color);
+    float dist = 0.f;
+    if (point) {
+        direction = hit.pos - ld3(L.vec);
+        dist = mag3(direction);
+        direction = normalize3(direction);
+        float dissipation = 4.f * PT_PI * dist * dist;
+        color = color / dissipation;
+    } else {
+        direction = ld3(L.vec);
+    }
+    f3 so = hit.pos + hit.normal * 0.00001f;  // NORMAL_BIAS (mod.rs:58)
+    f3 sd = -1.f * direction;
+    if (COUNT) lc.shadow_rays++;
+
+    if (!S.has_translucent) {
+        // Every opacity is exactly 1: the first list entry that passes the range
+        // test zeroes the colour, so "any hit in range" decides.
+        bool blocked = false;
+        float dlen = mag3(sd);
+        float key_scale = dlen < 1.0f ? dlen : 1.0f;
+        // hits farther than the light cannot pass the range test (|so + sd*t - pos| > dist)
+        float limit = point ? (dist + 1e-4f) * 1.0001f : INFINITY;
+        kd_traverse<COUNT>(S, so, sd, 0.f, key_scale, limit, lc, [&](uint32_t first, uint32_t n) {
+            const float4* lp = S.leaf_prims + (size_t)first * 3;
+            for (uint32_t i = 0; i < n; ++i) {
+                float4 q0 = lp[3 * i], q1 = lp[3 * i + 1], q2 = lp[3 * i + 2];
+                uint32_t pid = __float_as_uint(q0.w);
+                if (COUNT) lc.tris++;
+                if (!(pid & PT_PRIM_SPHERE)) {
+                    float t, u, v;
+                    bool bf;
+                    if (!isect_triangle(so, sd, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), t,
+                                        u, v, bf))
+                        continue;
+                    if (point && mag3((so + sd * t) - hit.pos) > dist) continue;
+                    blocked = true;
+                    return true;
+                } else {
+                    float t[2], key[2];
+                    bool ex[2];
+                    int nh = isect_sphere(so, sd, mk3(q0.x, q0.y, q0.z), q1.x, t, key, ex);
+                    for (int k = 0; k < nh; ++k) {
+                        if (!(key[k] == key[k])) continue;
+                        if (point && mag3((so + sd * t[k]) - hit.pos) > dist) continue;
+                        blocked = true;
+                        return true;
+                    }
+                }
+            }
+            return false;
+        });
+        radiance = blocked ? color * 0.0f : color;
+        return;
+    }
+
+    // General case: walk the sorted hit list, attenuating by (1 - opacity).
+    float t_prev = -INFINITY;
+    uint32_t ord_prev = 0;
+    RawHit h;
+    bool first = true;
+    while (next_hit<COUNT>(S, so, sd, t_prev, ord_prev, h, lc)) {
+        if (COUNT && !first) lc.restarts++;
+        first = false;
+        float opacity;
+        if (point) {
+            f3 sp = so + sd * ((h.flags & 2u) ? h.u : h.key);
+            if (mag3(sp - hit.pos) > dist) break;
+            // the SHADED hit's kind / uv with the occluder's material (mod.rs:324)
+            uint32_t smodel = __float_as_uint(S.prim_attr[(size_t)(h.pid & ~PT_PRIM_SPHERE) * 4 + 3].w);
+            opacity = material_opacity(S, smodel, hit.sphere, hit.uv);
+        } else {
+            Surface sh;
+            make_surface(S, so, sd, h, sh);
+            opacity = material_opacity(S, sh.model, sh.sphere, sh.uv);
+        }
+        color = color * (1.f - opacity);
+        if (sum3(color) == 0.f) break;
+        t_prev = h.key;
+        ord_prev = h.ord;
+    }
+    radiance = color;
+}
+
+// ---------------------------------------------------------------------------
+// Path (render_pixel + compute_radiance)
+// ---------------------------------------------------------------------------
+template <bool COUNT>
+PT_D f3 render_path(const DevScene& S, uint32_t bounces, f3 o, f3 d, PtRng& rng, uint32_t* slab, uint32_t tid,
+                    LocalCtr& lc) {
+    f3 color = mk3(0.f, 0.f, 0.f), thr = mk3(1.f, 1.f, 1.f);
+    for (uint32_t bounce = 0; bounce <= bounces; ++bounce) {
+        if (COUNT) lc.segments++;
+        // alpha walk over the sorted hit list (mod.rs:188-205)
+        Surface surf;
+        MatSample ms;
+        f3 normal = mk3(0.f, 0.f, 0.f);
+        bool have = false;
+        float t_prev = -INFINITY;
+        uint32_t ord_prev = 0;
+        RawHit h;
+        while (next_hit<COUNT>(S, o, d, t_prev, ord_prev, h, lc)) {
+            if (COUNT && have) lc.restarts++;
+            make_surface(S, o, d, h, surf);
+            material_sample(S, surf.model, surf.sphere, surf.uv, ms);
+            normal = shading_normal(S, surf);
+            have = true;
+            if (COUNT) lc.shaded++;
+            float opacity = ms.opacity;
+            if (opacity >= 1.f || (opacity > 0.001f && pt_rng_f32(rng, slab, tid) < opacity)) break;
+            t_prev = h.key;
+            ord_prev = h.ord;
+        }
+        if (!have) return color + mul_ew(thr, ld3(S.background));
+
+        f3 view = -1.f * d;
+        Brdf brdf;
+        ct_init(brdf, ms);
+        color = color + mul_ew(thr, ms.emissive);
+        for (uint32_t li = 0; li < S.n_lights; ++li) {
+            f3 lrad, ldir;
+            light_radiance<COUNT>(S, S.lights[li], surf, lrad, ldir, lc);
+            if (lrad.x == 0.f && lrad.y == 0.f && lrad.z == 0.f) continue;
+            f3 rl = -1.f * ldir;
+            color = color + mul_ew(mul_ew(thr, ct_eval_direct(brdf, normal, view, rl)), lrad);
+        }
+        if (bounce < bounces) {
+            o = surf.pos + surf.normal * 0.00001f;
+            float r1 = pt_rng_f32(rng, slab, tid);
+            float r2 = pt_rng_f32(rng, slab, tid);
+            d = ct_sample(brdf, normal, view, r1, r2);
+            f3 w = ct_eval_indirect(brdf, normal, view, d) / 1.0f;  // / brdf.pdf()
+            thr = mul_ew(thr, w);
+        }
+        if (dot3(thr, thr) < 0.00001f) return color;
+        if (bounce > 3) {  // russian_roulette (utils.rs:23-31)
+            float p = max_rs(max_rs(thr.x, thr.y), thr.z);
+            thr = thr * (1.f / p);
+            if (pt_rng_f32(rng, slab, tid) > p) return color;
+        }
+    }
+    return color;
+}
+
+// Camera ray (mod.rs:107-124)
+PT_D void primary_ray(const DevScene& S, uint32_t x, uint32_t y, uint32_t width, uint32_t height, float r1, float r2,
+                      f3& o, f3& d) {
+    float wf = (float)width, hf = (float)height;
+    float ratio = wf / hf;
+    float sx = (float)x + r1;
+    sx = sx / wf * 2.f - 1.f;
+    sx *= S.tan_half_fov * ratio;
+    float sy = (float)y + r2;
+    sy = 1.f - sy / hf * 2.f;
+    sy *= S.tan_half_fov;
+    f3 dir = normalize3(mk3(sx, sy, -1.f));
+    f3 c0 = ld3(S.cam_c0), c1 = ld3(S.cam_c1), c2 = ld3(S.cam_c2), c3 = ld3(S.cam_c3);
+    d = c0 * dir.x + c1 * dir.y + c2 * dir.z + c3 * 0.0f;
+    o = c3;
+}
+
+// tonemap + gamma + u8 (tonemap.rs:15-54, mod.rs:335-353)
+PT_D f3 tonemap(int type, f3 c) {
+    if (type == PT_TONEMAP_REINHARD) return div_ew(c, c + mk3(1.f, 1.f, 1.f));
+    if (type == PT_TONEMAP_ACES) {
+        f3 num = mul_ew(c, 2.51f * c + mk3(0.03f, 0.03f, 0.03f));
+        f3 den = mul_ew(c, 2.43f * c + mk3(0.59f, 0.59f, 0.59f)) + mk3(0.14f, 0.14f, 0.14f);
+        f3 r = div_ew(num, den);
+        auto cl = [](float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); };
+        return mk3(cl(r.x), cl(r.y), cl(r.z));
+    }
+    f3 col = c - mk3(0.004f, 0.004f, 0.004f);
+    col = mk3(max_rs(col.x, 0.f), max_rs(col.y, 0.f), max_rs(col.z, 0.f));
+    f3 num = mul_ew(col, 6.2f * col + mk3(0.5f, 0.5f, 0.5f));
+    f3 den = mul_ew(col, 6.2f * col + mk3(1.7f, 1.7f, 1.7f)) + mk3(0.06f, 0.06f, 0.06f);
+    return div_ew(num, den);
+}
