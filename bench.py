@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of the path-tracing hot path on N MI355X.
+
+Workload (BASELINE.json config 3, the one the metric is quoted on): the deterministic PS5
+stand-in scene (500 k triangles, seed 0; the real PS5 ISF is not in the reference), 1920x1080,
+128 spp, 5 bounces, Cook–Torrance, FILMIC.  A "step" is one complete render of that frame:
+every rank renders its interleaved 32x32 tiles (global pixel index in the seed formula, so
+the image is bit-identical for any N), then — for N > 1 — one RCCL all-gather of the packed
+u8 framebuffer slices and a scatter into the row-major image on every rank.  The scene, KD-tree
+and textures are resident in HBM before the timed region starts.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant
+kernel, HIP-event timed inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle —
+a port, all host cores — on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def bytes_per_sample(c, spp):
+    """SURVEY §8-d algorithmic bytes per path sample from exact work counters."""
+    n = max(1, c["samples"])
+    r_seg, r_sh = c["segments"] / n, c["shadow_rays"] / n
+    v, t, h = c["nodes_visited"] / n, c["tris_tested"] / n, c["shaded_hits"] / n
+    floor = r_seg * 160 + r_sh * 104 + 15.0 / spp
+    ceiling = floor + 8 * v + 36 * t + 160 * h
+    return floor, ceiling, dict(R_seg=r_seg, R_sh=r_sh, V=v, T=t, H=h)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tris", type=int, default=500_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=128)
+    ap.add_argument("--bounces", type=int, default=5)
+    ap.add_argument("--tonemap", default="FILMIC")
+    ap.add_argument("--scene-flags", type=int, default=0, help="1 = translucent shells (config 5)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--no-counters", action="store_true")
+    ap.add_argument("--save-png", default=None)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pta = entry.load_package()
+    lib = pta.gpu_lib()
+
+    # ---- scene (resident before the timed region)
+    t0 = time.time()
+    scene = pta.HostScene.generate_ps5(args.tris, 0, args.scene_flags)
+    gscene = pta.GpuScene(scene, device=local_rank)
+    info = gscene.info().as_dict()
+    setup_s = time.time() - t0
+
+    prof = pta.Profile.make(args.width, args.height, args.spp, args.bounces, args.tonemap)
+    tile = 32
+    opts = pta.Opts.make(flags=pta.PT_FLAG_TIMING, device=local_rank, shard_rank=rank, shard_count=world,
+                         tile_w=tile, tile_h=tile)
+    n_local = int(lib.pt_local_pixel_count(C.byref(prof), C.byref(opts)))
+    npix = args.width * args.height
+    slice_pixels = n_local
+    if world > 1:
+        t = torch.tensor([n_local], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        slice_pixels = int(t.item())
+    rgb_local = torch.zeros(slice_pixels * 3, dtype=torch.uint8, device=dev)
+    acc_local = torch.zeros(max(1, n_local) * 3, dtype=torch.float32, device=dev)
+    gathered = torch.zeros(world * slice_pixels * 3, dtype=torch.uint8, device=dev) if world > 1 else None
+    image = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    kernel_ms, launches = [0.0], [0]
+
+    def step():
+        gscene.render_device(prof, opts, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
+        tm = gscene.timing()
+        kernel_ms[0] += tm.integrate_ms
+        launches[0] += tm.launches
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, rgb_local)
+            pta.check_gpu(lib.pt_assemble_tiles(C.byref(prof), world, tile, tile, slice_pixels, 3,
+                                                gathered.data_ptr(), image.data_ptr(), stream))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms[0], launches[0] = 0.0, 0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = npix * args.spp * args.steps
+    value = total_samples / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel (k_render), rank 0's shard
+    roofline = None
+    counters = None
+    if not args.no_counters:
+        copts = pta.Opts.make(flags=pta.PT_FLAG_COUNTERS, device=local_rank, shard_rank=rank, shard_count=world,
+                              tile_w=tile, tile_h=tile)
+        gscene.render_device(prof, copts, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
+        torch.cuda.synchronize()
+        counters = gscene.counters().as_dict()
+        floor_b, ceil_b, per = bytes_per_sample(counters, args.spp)
+        avg_ms = kernel_ms[0] / max(1, launches[0])
+        samples_per_launch = n_local * args.spp / max(1, launches[0] // args.steps)
+        achieved = ceil_b * samples_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "latest_traffic.json"
+        if tf.exists():
+            try:
+                rec = json.loads(tf.read_text())
+                if rec.get("workload") == [args.tris, args.width, args.height, args.spp, args.bounces, world]:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_sample": round(ceil_b, 1),
+                    "queue_floor_bytes_per_sample": round(floor_b, 1),
+                    "queue_floor_frac": round(floor_b * samples_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "per_sample": {k: round(v, 3) for k, v in per.items()}}
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only)
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        oracle = entry.load_oracle()
+        osc = oracle.OracleScene(scene.desc, oracle.PTO_BVH)
+        rows_per_band, n_bands = 2, 12
+        done, t_cpu = 0, 0.0
+        bands = []
+        for b in range(n_bands):
+            y0 = int((b + 0.5) * args.height / n_bands)
+            begin, end = y0 * args.width, min(npix, (y0 + rows_per_band) * args.width)
+            t1 = time.perf_counter()
+            osc.render(prof, begin, end, 0)
+            t_cpu += time.perf_counter() - t1
+            done += (end - begin) * args.spp
+            bands.append(y0)
+            if t_cpu > args.cpu_seconds:
+                break
+        cpu = {"value": round(done / t_cpu / 1e6, 4), "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"{len(bands)} bands of {rows_per_band} rows spread over the frame "
+                         f"({done} of {npix * args.spp} samples, {t_cpu:.1f} s), oracle/pt_oracle.cpp with its "
+                         f"AABB-tree candidate filter, OpenMP on all host cores"}
+
+    if args.save_png and rank == 0:
+        img = (image if world > 1 else rgb_local[: npix * 3]).cpu().numpy()
+        pta.check_host(pta.host_lib().pth_png_write_rgb8(os.fsencode(args.save_png), args.width, args.height,
+                                                         img.ctypes.data))
+
+    if rank == 0:
+        out = {
+            "metric": "Msamples/sec (WxHxspp/s), PS5 stand-in scene, Cook-Torrance + FILMIC",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PS5 stand-in {scene.n_triangles} triangles (generator seed 0, flags "
+                                   f"{args.scene_flags}), {args.width}x{args.height}, {args.spp} spp, "
+                                   f"{args.bounces} bounces, COOK_TORRANCE, {args.tonemap}",
+                       "parallelism": f"{world} x tile-sharded (32x32 interleaved)" + (", RCCL all-gather of u8 framebuffer" if world > 1 else ""),
+                       "kd": {k: info[k] for k in ("n_prims", "n_kd_nodes", "n_kd_leaves", "n_leaf_refs", "kd_depth")},
+                       "setup_seconds": round(setup_s, 2), "kd_build_seconds": round(info["kd_build_seconds"], 2)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if counters:
+            out["counters"] = counters
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

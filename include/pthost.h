@@ -78,6 +78,10 @@ typedef struct pth_kdtree {
     pth_kd_node* nodes;     /* malloc'd */
     uint32_t* refs;         /* malloc'd: primitive ids, leaf after leaf */
     double build_seconds;
+    /* surface-area expectation for a random line through the root box:
+     * interior nodes visited and primitive tests per ray */
+    double expected_nodes;
+    double expected_tests;
 } pth_kdtree;
 
 /* Primitive ids: one id per triangle and per sphere, in model order (a

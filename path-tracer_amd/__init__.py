@@ -116,7 +116,7 @@ class KdTree(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_refs", C.c_uint64), ("n_leaves", C.c_uint64),
                 ("depth", C.c_uint32), ("_pad", C.c_uint32), ("bounds_min", C.c_float * 3),
                 ("bounds_max", C.c_float * 3), ("nodes", C.POINTER(KdNode)), ("refs", C.POINTER(C.c_uint32)),
-                ("build_seconds", C.c_double)]
+                ("build_seconds", C.c_double), ("expected_nodes", C.c_double), ("expected_tests", C.c_double)]
 
 
 class OracleStats(C.Structure):

@@ -85,9 +85,12 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
             uint32_t below = node + 1, above = nd.y >> 2;
             uint32_t first = below_first ? below : above;
             uint32_t second = below_first ? above : below;
-            if (tplane > tmax || tplane <= 0.f) {
+            // A primitive touching the split plane lives on one side only (kd_build.cpp), so a
+            // hit AT the plane must see both children: the one-child shortcuts keep a
+            // relative epsilon of distance from the interval ends.
+            if (tplane > tmax * PT_EXIT_REL + PT_EXIT_ABS || tplane <= 0.f) {
                 node = first;
-            } else if (tplane < tmin) {
+            } else if (tplane < tmin * (2.f - PT_EXIT_REL) - PT_EXIT_ABS) {
                 node = second;
             } else {  // also taken when tplane is NaN: visit both (conservative)
                 st_node[sp] = second;

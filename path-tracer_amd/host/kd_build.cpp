@@ -13,12 +13,17 @@
 //
 // Robustness rules that keep the "never drop a hit" property:
 //   * primitives are assigned to children by their exact f32 AABB (no
-//     clipping), with closed comparisons, so a primitive touching the split
-//     plane lands on every side it touches;
+//     clipping): below = { min < split }, above = { max > split }, primitives
+//     lying IN the plane go to the cheaper side.  A primitive that merely touches the
+//     plane from one side is NOT duplicated (on tessellated meshes, where
+//     split planes sit on shared vertices, duplicating them multiplies the
+//     leaf references ~10x);
 //   * split positions are primitive AABB bounds (exact f32 values);
-//   * the device traversal accepts hits outside the current leaf interval
-//     and keeps walking while the next node starts before the best hit
-//     (plus a relative slack), see csrc/pt_kernels.hip.
+//   * in exchange the device traversal visits BOTH children whenever the
+//     plane parameter lies within a relative epsilon of the node's ray
+//     interval, accepts hits outside the current leaf interval, and keeps
+//     walking while the next node starts before the best hit (plus slack),
+//     see csrc/pt_integrator.h kd_traverse().
 //
 // Cost model: surface-area heuristic with exact sweep over AABB edges
 // (after Wald & Havran / pbrt's KdTreeAccel), traversal cost 1, empty bonus
@@ -51,6 +56,7 @@ struct Sub {
     std::vector<uint32_t> refs;
     uint32_t depth = 0;
     uint64_t leaves = 0;
+    double sa_interior = 0, sa_tests = 0;  // un-normalised surface-area sums
 };
 
 struct Builder {
@@ -60,8 +66,15 @@ struct Builder {
     float empty_bonus = 0.5f;
     uint32_t max_leaf;
     int par_levels;
+    size_t strict_below = 64;
 
-    void leaf(Sub& out, const std::vector<uint32_t>& prims, uint32_t level) {
+    static double area(const Box& b) {
+        double dx = (double)b.mx[0] - b.mn[0], dy = (double)b.mx[1] - b.mn[1], dz = (double)b.mx[2] - b.mn[2];
+        return 2.0 * (dx * dy + dx * dz + dy * dz);
+    }
+
+    void leaf(Sub& out, const Box& nb, const std::vector<uint32_t>& prims, uint32_t level) {
+        out.sa_tests += area(nb) * (double)prims.size();
         pth_kd_node n;
         n.w0 = (uint32_t)out.refs.size();
         n.w1 = ((uint32_t)prims.size() << 2) | 3u;
@@ -75,7 +88,7 @@ struct Builder {
                uint32_t level) {
         const size_t n = prims.size();
         if (n <= max_leaf || depth_left == 0) {
-            leaf(out, prims, level);
+            leaf(out, nb, prims, level);
             return;
         }
         // SAH sweep
@@ -85,64 +98,89 @@ struct Builder {
         float old_cost = isect_cost * (float)n;
         float best_cost = INFINITY;
         int best_axis = -1;
-        size_t best_offset = 0;
-        std::vector<Edge> edges(2 * n), best_edges;
+        std::vector<Edge> edges(2 * n);
+        float best_split = 0.f;
+        bool best_planar_below = true;
         int axis = d[0] > d[1] ? (d[0] > d[2] ? 0 : 2) : (d[1] > d[2] ? 1 : 2);
-        for (int retry = 0; retry < 3; ++retry) {
+        for (int retry = 0; retry < 3; ++retry, axis = (axis + 1) % 3) {
+            if (!(d[axis] > 0.f)) continue;  // flat box: nothing to cut on this axis
+            const float lo = nb.mn[axis], hi = nb.mx[axis];
             for (size_t i = 0; i < n; ++i) {
                 const Box& b = boxes[prims[i]];
-                edges[2 * i] = {b.mn[axis], prims[i] << 1};
-                edges[2 * i + 1] = {b.mx[axis], (prims[i] << 1) | 1u};
+                // AABBs are not clipped, so clamp their edges to the node (a primitive may
+                // stick out of the box it was sorted into)
+                edges[2 * i] = {std::max(b.mn[axis], lo), prims[i] << 1};
+                edges[2 * i + 1] = {std::min(b.mx[axis], hi), (prims[i] << 1) | 1u};
             }
-            std::sort(edges.begin(), edges.end(), [](const Edge& a, const Edge& b) {
-                if (a.t != b.t) return a.t < b.t;
-                return (a.key & 1u) < (b.key & 1u);  // starts before ends
-            });
+            std::sort(edges.begin(), edges.end(), [](const Edge& a, const Edge& b) { return a.t < b.t; });
+            // Candidate planes = distinct (clamped) AABB bounds.  For a plane at t:
+            //   L = { min < t }, R = { max > t }, P = { min == max == t } (lying in the plane)
+            // A primitive that only touches the plane from one side stays on that side; P goes
+            // to whichever side is cheaper.  A plane ON the node boundary is allowed when it
+            // peels planar primitives into a zero-thickness child (a ground plane at the
+            // bottom of the scene box): rays that never reach the plane skip them entirely.
             size_t n_below = 0, n_above = n;
             int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
-            for (size_t i = 0; i < 2 * n; ++i) {
-                if (edges[i].key & 1u) --n_above;
+            for (size_t i = 0; i < 2 * n;) {
                 float t = edges[i].t;
-                if (t > nb.mn[axis] && t < nb.mx[axis]) {
-                    float below_sa = 2.f * (d[a1] * d[a2] + (t - nb.mn[axis]) * (d[a1] + d[a2]));
-                    float above_sa = 2.f * (d[a1] * d[a2] + (nb.mx[axis] - t) * (d[a1] + d[a2]));
-                    float pb = below_sa * inv_total_sa, pa = above_sa * inv_total_sa;
-                    float eb = (n_above == 0 || n_below == 0) ? empty_bonus : 0.f;
-                    float cost = trav_cost + isect_cost * (1.f - eb) * (pb * (float)n_below + pa * (float)n_above);
-                    if (cost < best_cost) {
-                        best_cost = cost;
-                        best_axis = axis;
-                        best_offset = i;
+                size_t j = i, ends = 0, starts = 0, planar = 0;
+                for (; j < 2 * n && edges[j].t == t; ++j) {
+                    if (edges[j].key & 1u) ++ends;
+                    else {
+                        ++starts;
+                        const Box& b = boxes[edges[j].key >> 1];
+                        if (std::min(b.mx[axis], hi) == t) ++planar;
                     }
                 }
-                if (!(edges[i].key & 1u)) ++n_below;
+                n_above -= ends;
+                const bool at_lo = t == lo, at_hi = t == hi;
+                if ((!at_lo && !at_hi) || planar > 0) {
+                    float below_sa = 2.f * (d[a1] * d[a2] + (t - lo) * (d[a1] + d[a2]));
+                    float above_sa = 2.f * (d[a1] * d[a2] + (hi - t) * (d[a1] + d[a2]));
+                    float pb = below_sa * inv_total_sa, pa = above_sa * inv_total_sa;
+                    for (int side = 0; side < 2; ++side) {
+                        bool planar_below = side == 0;
+                        if (at_lo && !planar_below) continue;  // would reproduce the parent
+                        if (at_hi && planar_below) continue;
+                        if (planar == 0 && !planar_below) continue;
+                        size_t nbel = n_below + (planar_below ? planar : 0);
+                        size_t nabv = n_above + (planar_below ? 0 : planar);
+                        float eb = (nabv == 0 || nbel == 0) ? empty_bonus : 0.f;
+                        float cost = trav_cost + isect_cost * (1.f - eb) * (pb * (float)nbel + pa * (float)nabv);
+                        if (cost < best_cost) {
+                            best_cost = cost;
+                            best_axis = axis;
+                            best_split = t;
+                            best_planar_below = planar_below;
+                        }
+                    }
+                }
+                n_below += starts;
+                i = j;
             }
-            if (best_axis != -1) {
-                best_edges.swap(edges);  // sorted edges of the winning axis
-                break;
-            }
-            axis = (axis + 1) % 3;  // no split plane strictly inside the node: try the next axis
+            if (best_axis != -1) break;  // otherwise: no usable plane on this axis, try the next
         }
         if (best_cost > old_cost) ++bad;
-        if ((best_cost > 4.f * old_cost && n < 16) || best_axis == -1 || bad == 3) {
-            leaf(out, prims, level);
+        // small nodes stop as soon as splitting no longer pays (Wald's automatic
+        // termination); large ones tolerate a few bad refines like pbrt does
+        if (best_axis == -1 || bad == 3 || (best_cost >= old_cost && n <= strict_below)) {
+            leaf(out, nb, prims, level);
             return;
         }
-        // classify
+        // classify (prims is in ascending id order, so both children stay sorted)
         std::vector<uint32_t> below, above;
         below.reserve(n);
         above.reserve(n);
-        for (size_t i = 0; i < best_offset; ++i)
-            if (!(best_edges[i].key & 1u)) below.push_back(best_edges[i].key >> 1);
-        for (size_t i = best_offset + 1; i < 2 * n; ++i)
-            if (best_edges[i].key & 1u) above.push_back(best_edges[i].key >> 1);
-        float split = best_edges[best_offset].t;
+        for (uint32_t p : prims) {
+            const Box& b = boxes[p];
+            float mn = std::max(b.mn[best_axis], nb.mn[best_axis]), mx = std::min(b.mx[best_axis], nb.mx[best_axis]);
+            bool planar = mn == best_split && mx == best_split;
+            if (mn < best_split || (planar && best_planar_below)) below.push_back(p);
+            if (mx > best_split || (planar && !best_planar_below)) above.push_back(p);
+        }
+        float split = best_split;
         std::vector<Edge>().swap(edges);
-        std::vector<Edge>().swap(best_edges);
         std::vector<uint32_t>().swap(prims);
-        // leaf refs keep ascending primitive order (deterministic tie order)
-        std::sort(below.begin(), below.end());
-        std::sort(above.begin(), above.end());
 
         Box bb = nb, ab = nb;
         bb.mx[best_axis] = split;
@@ -150,6 +188,7 @@ struct Builder {
 
         size_t me = out.nodes.size();
         out.nodes.push_back({0, 0});
+        out.sa_interior += area(nb);
         uint32_t above_idx;
         if ((int)level < par_levels && n > 20000) {
             auto fut = std::async(std::launch::async, [&, this]() {
@@ -170,6 +209,8 @@ struct Builder {
             out.refs.insert(out.refs.end(), sub->refs.begin(), sub->refs.end());
             out.depth = std::max(out.depth, sub->depth);
             out.leaves += sub->leaves;
+            out.sa_interior += sub->sa_interior;
+            out.sa_tests += sub->sa_tests;
         } else {
             build(out, bb, std::move(below), depth_left - 1, bad, level + 1);
             above_idx = (uint32_t)out.nodes.size();
@@ -239,9 +280,11 @@ static void kd_build(const pt_scene_desc& d, pth_kdtree& out) {
     if (n == 0)
         for (int a = 0; a < 3; ++a) root.mn[a] = root.mx[a] = 0.f;
 
-    Builder b{boxes, env_float("PT_KD_ISECT_COST", 24.f)};
+    Builder b{boxes, env_float("PT_KD_ISECT_COST", 24.f), 1.0f, 0.5f, 2, 4, 64};
     b.max_leaf = (uint32_t)env_float("PT_KD_MAX_LEAF", 2.f);
     b.par_levels = (int)env_float("PT_KD_PAR_LEVELS", 4.f);
+    b.strict_below = (size_t)env_float("PT_KD_STRICT_BELOW", 64.f);
+    b.empty_bonus = env_float("PT_KD_EMPTY_BONUS", 0.5f);
     int max_depth = n ? (int)std::lround(8 + 1.3 * std::log2((double)n)) : 0;
     if (max_depth > 62) max_depth = 62;  // device traversal stack bound
     max_depth = (int)env_float("PT_KD_MAX_DEPTH", (float)max_depth);
@@ -262,6 +305,9 @@ static void kd_build(const pt_scene_desc& d, pth_kdtree& out) {
     if (!out.nodes || !out.refs) throw std::bad_alloc();
     memcpy(out.nodes, sub.nodes.data(), sub.nodes.size() * sizeof(pth_kd_node));
     memcpy(out.refs, sub.refs.data(), sub.refs.size() * sizeof(uint32_t));
+    double root_area = Builder::area(root);
+    out.expected_nodes = root_area > 0 ? sub.sa_interior / root_area : 0;
+    out.expected_tests = root_area > 0 ? sub.sa_tests / root_area : 0;
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
