@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -139,6 +140,178 @@ __global__ __launch_bounds__(256) void k_render(DevScene S, RenderParams P, cons
         atomicAdd(&ctr->rng_draws, (unsigned long long)draws);
         atomicAdd(&ctr->restarts, (unsigned long long)lc.restarts);
     }
+}
+
+// ------------------------------------------------------------------ persistent integrator
+// Work item w of a sample batch = one path sample:
+//     w = (block64 * batch + s_rel) * 64 + lane
+// block64 enumerates the 8x8 pixel blocks of this call's tiles, so 64 consecutive items are one
+// coherent 8x8 block of primary rays of the same sample, and consecutive groups are the next
+// samples of the same block (the CUs stay on one image region: better L2 locality per XCD).
+struct ItemRef {
+    uint32_t x, y, global_index, out_index, sample;  // sample is 1-based (mod.rs:105)
+    bool valid;
+};
+
+__device__ __forceinline__ ItemRef decode_item(const RenderParams& P, const uint32_t* __restrict__ tile_offsets,
+                                               uint32_t item) {
+    ItemRef r;
+    uint32_t batch = P.sample_end - P.sample_begin;
+    uint32_t lane = item & 63u;
+    uint32_t g = item >> 6;
+    uint32_t s_rel = g % batch, b64 = g / batch;
+    uint32_t blocks_per_tile = (P.tile_w >> 3) * (P.tile_h >> 3);
+    uint32_t lt = b64 / blocks_per_tile, sub = b64 % blocks_per_tile;
+    uint32_t waves_x = P.tile_w >> 3;
+    uint32_t tx = (sub % waves_x) * 8u + (lane & 7u);
+    uint32_t ty = (sub / waves_x) * 8u + (lane >> 3);
+    uint32_t k = P.shard_rank + lt * P.shard_count;
+    uint32_t tile_x = k % P.tiles_x, tile_y = k / P.tiles_x;
+    r.x = tile_x * P.tile_w + tx;
+    r.y = tile_y * P.tile_h + ty;
+    r.valid = tile_y < P.tiles_y && r.x < P.width && r.y < P.height;
+    r.global_index = r.x + r.y * P.width;
+    r.sample = P.sample_begin + 1u + s_rel;
+    if (P.shard_count <= 1) {
+        r.out_index = r.global_index;
+    } else {
+        uint32_t cw = min(P.tile_w, P.width - tile_x * P.tile_w);
+        r.out_index = tile_offsets[lt] + ty * cw + tx;
+    }
+    return r;
+}
+
+// First ChaCha12 block of every work item, word-major ([16][n_items]) so that the lanes of
+// a wavefront store 16 coalesced rows.  A fully converged kernel: ~700 integer ops per item.
+__global__ __launch_bounds__(256) void k_rng_blocks(RenderParams P, const uint32_t* __restrict__ tile_offsets,
+                                                    uint32_t n_items, uint32_t* __restrict__ blocks) {
+    uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    if (item >= n_items) return;
+    ItemRef it = decode_item(P, tile_offsets, item);
+    if (!it.valid) return;
+    uint32_t w[16];
+    pt_chacha12_block((uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)P.samples, 0u, w);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) blocks[(size_t)i * n_items + item] = w[i];
+}
+
+// rng.gen::<f32>() number `idx` of work item `item`: the first block comes from k_rng_blocks,
+// later blocks (paths with more than 16 draws — rare) are regenerated in registers.
+__device__ __forceinline__ float item_draw(const uint32_t* __restrict__ blocks, uint32_t n_items, uint32_t item,
+                                           uint64_t seed, uint32_t idx) {
+    uint32_t word;
+    if (idx < 16u) {
+        word = blocks[(size_t)idx * n_items + item];
+    } else {
+        uint32_t w[16];
+        pt_chacha12_block(seed, idx >> 4, w);
+        word = w[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) word = (idx & 15u) == (uint32_t)i ? w[i] : word;
+    }
+    return (float)(word >> 8) * (1.0f / 16777216.0f);
+}
+
+// Persistent-threads integrator with path regeneration.  Every lane runs the loop
+//     fetch a work item if idle -> one bounce-loop iteration -> retire the sample when done
+// so the lanes of a wavefront sit in the same code (traversal / shading) on different samples
+// and bounces.  Work is fetched with one atomic per wavefront: ballot of the idle lanes,
+// popcount for the amount, mbcnt prefix for each lane's slot.  The sample's radiance goes to
+// staging[s_rel][pixel]; k_accumulate adds the samples in order afterwards, so the f32 sum per
+// pixel is the reference's `*pixel += color` sequence (mod.rs:130).
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_render_persist(DevScene S, RenderParams P,
+                                                        const uint32_t* __restrict__ tile_offsets,
+                                                        const uint32_t* __restrict__ rng_blocks, uint32_t n_items,
+                                                        float* __restrict__ staging, uint32_t* __restrict__ work_counter,
+                                                        DevCounters* __restrict__ ctr) {
+    const uint32_t lane = __lane_id();
+    PathState ps;
+    uint32_t item = 0, out_slot = 0, draw_idx = 0;
+    uint64_t seed = 0;
+    bool active = false, exhausted = false;
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};
+    uint32_t n_samples = 0, n_draws = 0;
+    while (true) {
+        // ---- regeneration: idle lanes take the next items
+        bool need = !active && !exhausted;
+        unsigned long long m = __ballot(need);
+        if (m) {
+            uint32_t cnt = (uint32_t)__popcll(m);
+            int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(work_counter, cnt);
+            base = __shfl(base, leader);
+            if (need) {
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                uint32_t w = base + rank;
+                if (w >= n_items || base + rank < base) {
+                    exhausted = true;
+                } else {
+                    ItemRef it = decode_item(P, tile_offsets, w);
+                    if (it.valid) {
+                        item = w;
+                        seed = (uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)P.samples;
+                        out_slot = (it.sample - 1u - P.sample_begin) * P.n_local + it.out_index;
+                        float r1 = item_draw(rng_blocks, n_items, item, seed, 0u);
+                        float r2 = item_draw(rng_blocks, n_items, item, seed, 1u);
+                        draw_idx = 2;
+                        f3 o, d;
+                        primary_ray(S, it.x, it.y, P.width, P.height, r1, r2, o, d);
+                        path_begin(ps, o, d);
+                        active = true;
+                    }
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (__all(exhausted)) break;
+            continue;
+        }
+        if (active) {
+            bool done = path_step<COUNT>(S, P.bounces, ps, lc, [&]() {
+                return item_draw(rng_blocks, n_items, item, seed, draw_idx++);
+            });
+            if (done) {
+                float* out = staging + (size_t)out_slot * 3;
+                out[0] = ps.color.x;
+                out[1] = ps.color.y;
+                out[2] = ps.color.z;
+                active = false;
+                if (COUNT) {
+                    n_samples++;
+                    n_draws += draw_idx;
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->samples, (unsigned long long)n_samples);
+        atomicAdd(&ctr->segments, (unsigned long long)lc.segments);
+        atomicAdd(&ctr->shadow_rays, (unsigned long long)lc.shadow_rays);
+        atomicAdd(&ctr->nodes_visited, (unsigned long long)lc.nodes);
+        atomicAdd(&ctr->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&ctr->shaded_hits, (unsigned long long)lc.shaded);
+        atomicAdd(&ctr->rng_draws, (unsigned long long)n_draws);
+        atomicAdd(&ctr->restarts, (unsigned long long)lc.restarts);
+    }
+}
+
+// accum[p] (+)= staging[0][p] + staging[1][p] + ... in sample order: the reference's
+// `*pixel += color` once per sample pass (mod.rs:105,130).
+__global__ __launch_bounds__(256) void k_accumulate(const float* __restrict__ staging, float* __restrict__ accum,
+                                                    uint32_t n_local, uint32_t batch, int first) {
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_local) return;
+    f3 acc = mk3(0.f, 0.f, 0.f);
+    if (!first) acc = mk3(accum[3 * (size_t)p], accum[3 * (size_t)p + 1], accum[3 * (size_t)p + 2]);
+    for (uint32_t s = 0; s < batch; ++s) {
+        const float* v = staging + ((size_t)s * n_local + p) * 3;
+        acc = acc + mk3(v[0], v[1], v[2]);
+    }
+    accum[3 * (size_t)p] = acc.x;
+    accum[3 * (size_t)p + 1] = acc.y;
+    accum[3 * (size_t)p + 2] = acc.z;
 }
 
 __global__ __launch_bounds__(256) void k_postprocess(const float* __restrict__ accum, uint8_t* __restrict__ rgb8,
@@ -330,7 +503,8 @@ struct pt_scene {
     pt_scene_info info{};
     mutable pt_timing timing{};
     mutable pt_counters counters{};
-    mutable DeviceBuffer accum_scratch, tile_table, counter_buf;
+    mutable DeviceBuffer accum_scratch, tile_table, counter_buf, staging_buf, rng_buf, work_counter;
+    mutable int persist_blocks = 0;
     mutable std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> tile_key{0, 0, 0, 0, 0, 0};
     mutable std::vector<hipEvent_t> events;
 
@@ -550,22 +724,73 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     P.tiles_y = tm.tiles_y;
     P.n_local = (uint32_t)tm.n_local;
 
+    // ---- choose the integrator: persistent with path regeneration (default) or the plain
+    // one-lane-per-pixel megakernel (PT_INTEGRATOR=mega, kept for A/B measurements)
+    static const bool use_mega = [] {
+        const char* e = getenv("PT_INTEGRATOR");
+        return e && !strcmp(e, "mega");
+    }();
+    const uint32_t blocks64 = tm.n_local_tiles * (o.tile_w / 8u) * (o.tile_h / 8u);
+    // staging: 12 B radiance + 64 B RNG block per work item; default budget 32 GiB of the 288 GB
+    static const uint64_t budget = [] {
+        const char* e = getenv("PT_STAGING_GIB");
+        return (uint64_t)((e && *e ? atof(e) : 32.0) * 1024.0 * 1024.0 * 1024.0);
+    }();
     uint32_t batch = o.sample_batch ? o.sample_batch : p.samples;
+    if (!use_mega) {
+        uint64_t per_sample = (uint64_t)blocks64 * 64u * 64u + tm.n_local * 12u;
+        uint64_t max_batch = std::max<uint64_t>(1, budget / std::max<uint64_t>(1, per_sample));
+        max_batch = std::min<uint64_t>(max_batch, 0x7fffffffull / ((uint64_t)blocks64 * 64u));
+        if (max_batch == 0) fail(PT_ERR_UNSUPPORTED, "image too large for one sample batch");
+        batch = (uint32_t)std::min<uint64_t>(batch, max_batch);
+        if (s.persist_blocks == 0) {
+            int per_cu = 0, n_cu = 0;
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_persist<false>, 256, 0));
+            HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s.device));
+            s.persist_blocks = std::max(1, per_cu) * std::max(1, n_cu);
+        }
+        s.staging_buf.ensure((size_t)batch * tm.n_local * 12);
+        s.rng_buf.ensure((size_t)batch * blocks64 * 64u * 64u);
+        s.work_counter.ensure(256);
+    }
     uint32_t blocks = tm.n_local_tiles * (o.tile_w * o.tile_h / 256u);
     size_t ev = 0;
     uint32_t launches = 0;
     for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
         P.sample_begin = s0;
         P.sample_end = std::min(p.samples, s0 + batch);
-        if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
-        if (counting)
-            hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum,
-                               (DevCounters*)s.counter_buf.p);
-        else
-            hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum,
-                               (DevCounters*)nullptr);
-        HIP_CHECK(hipGetLastError());
-        if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+        if (use_mega) {
+            if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+            if (counting)
+                hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum,
+                                   (DevCounters*)s.counter_buf.p);
+            else
+                hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum,
+                                   (DevCounters*)nullptr);
+            HIP_CHECK(hipGetLastError());
+            if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+        } else {
+            uint32_t nb = P.sample_end - P.sample_begin;
+            uint32_t n_items = blocks64 * 64u * nb;
+            hipLaunchKernelGGL(k_rng_blocks, dim3((n_items + 255u) / 256u), dim3(256), 0, stream, P, d_tiles, n_items,
+                               (uint32_t*)s.rng_buf.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemsetAsync(s.work_counter.p, 0, 4, stream));
+            if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+            if (counting)
+                hipLaunchKernelGGL(k_render_persist<true>, dim3(s.persist_blocks), dim3(256), 0, stream, s.dev, P, d_tiles,
+                                   (const uint32_t*)s.rng_buf.p, n_items, (float*)s.staging_buf.p,
+                                   (uint32_t*)s.work_counter.p, (DevCounters*)s.counter_buf.p);
+            else
+                hipLaunchKernelGGL(k_render_persist<false>, dim3(s.persist_blocks), dim3(256), 0, stream, s.dev, P, d_tiles,
+                                   (const uint32_t*)s.rng_buf.p, n_items, (float*)s.staging_buf.p,
+                                   (uint32_t*)s.work_counter.p, (DevCounters*)nullptr);
+            HIP_CHECK(hipGetLastError());
+            if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+            hipLaunchKernelGGL(k_accumulate, dim3(((uint32_t)tm.n_local + 255u) / 256u), dim3(256), 0, stream,
+                               (const float*)s.staging_buf.p, accum, (uint32_t)tm.n_local, nb, s0 == 0 ? 1 : 0);
+            HIP_CHECK(hipGetLastError());
+        }
         ++launches;
         if (o.progress) {
             HIP_CHECK(hipStreamSynchronize(stream));

@@ -525,63 +525,98 @@ PT_D void light_radiance(const DevScene& S, const DevLight& L, const Surface& hi
 }
 
 // ---------------------------------------------------------------------------
-// Path (render_pixel + compute_radiance)
+// Path (render_pixel + compute_radiance), one bounce-loop iteration at a time.
+//
+// The reference's loop body (mod.rs:180-226) is exposed as path_step() so the
+// persistent kernel can interleave iterations of DIFFERENT samples in the lanes
+// of one wavefront: a lane whose path ends fetches its next work item while its
+// neighbours keep bouncing.  `draw()` returns the next rng.gen::<f32>().
 // ---------------------------------------------------------------------------
+struct PathState {
+    f3 o, d;         // current ray
+    f3 color, thr;   // RadianceInfo (mod.rs:41-48)
+    uint32_t bounce;
+};
+
+PT_D void path_begin(PathState& ps, f3 o, f3 d) {
+    ps.o = o;
+    ps.d = d;
+    ps.color = mk3(0.f, 0.f, 0.f);
+    ps.thr = mk3(1.f, 1.f, 1.f);
+    ps.bounce = 0;
+}
+
+// Runs iteration `ps.bounce` of the bounce loop.  Returns true when the path is
+// finished (ps.color is then the value render_pixel returns).
+template <bool COUNT, class DrawFn>
+PT_D bool path_step(const DevScene& S, uint32_t bounces, PathState& ps, LocalCtr& lc, DrawFn&& draw) {
+    const f3 o = ps.o, d = ps.d;
+    if (COUNT) lc.segments++;
+    // alpha walk over the sorted hit list (mod.rs:188-205)
+    Surface surf;
+    MatSample ms;
+    f3 normal = mk3(0.f, 0.f, 0.f);
+    bool have = false;
+    float t_prev = -INFINITY;
+    uint32_t ord_prev = 0;
+    RawHit h;
+    while (next_hit<COUNT>(S, o, d, t_prev, ord_prev, h, lc)) {
+        if (COUNT && have) lc.restarts++;
+        make_surface(S, o, d, h, surf);
+        material_sample(S, surf.model, surf.sphere, surf.uv, ms);
+        normal = shading_normal(S, surf);
+        have = true;
+        if (COUNT) lc.shaded++;
+        float opacity = ms.opacity;
+        if (opacity >= 1.f || (opacity > 0.001f && draw() < opacity)) break;
+        t_prev = h.key;
+        ord_prev = h.ord;
+    }
+    if (!have) {
+        ps.color = ps.color + mul_ew(ps.thr, ld3(S.background));
+        return true;
+    }
+    f3 view = -1.f * d;
+    Brdf brdf;
+    ct_init(brdf, ms);
+    f3 color = ps.color + mul_ew(ps.thr, ms.emissive);
+    for (uint32_t li = 0; li < S.n_lights; ++li) {
+        f3 lrad, ldir;
+        light_radiance<COUNT>(S, S.lights[li], surf, lrad, ldir, lc);
+        if (lrad.x == 0.f && lrad.y == 0.f && lrad.z == 0.f) continue;
+        f3 rl = -1.f * ldir;
+        color = color + mul_ew(mul_ew(ps.thr, ct_eval_direct(brdf, normal, view, rl)), lrad);
+    }
+    ps.color = color;
+    f3 thr = ps.thr;
+    if (ps.bounce < bounces) {
+        ps.o = surf.pos + surf.normal * 0.00001f;
+        float r1 = draw();
+        float r2 = draw();
+        ps.d = ct_sample(brdf, normal, view, r1, r2);
+        f3 w = ct_eval_indirect(brdf, normal, view, ps.d) / 1.0f;  // / brdf.pdf()
+        thr = mul_ew(thr, w);
+    }
+    if (dot3(thr, thr) < 0.00001f) return true;
+    if (ps.bounce > 3) {  // russian_roulette (utils.rs:23-31)
+        float p = max_rs(max_rs(thr.x, thr.y), thr.z);
+        thr = thr * (1.f / p);
+        if (draw() > p) return true;
+    }
+    ps.thr = thr;
+    ps.bounce++;
+    return ps.bounce > bounces;
+}
+
+// render_pixel for one sample (megakernel form).
 template <bool COUNT>
 PT_D f3 render_path(const DevScene& S, uint32_t bounces, f3 o, f3 d, PtRng& rng, uint32_t* slab, uint32_t tid,
                     LocalCtr& lc) {
-    f3 color = mk3(0.f, 0.f, 0.f), thr = mk3(1.f, 1.f, 1.f);
-    for (uint32_t bounce = 0; bounce <= bounces; ++bounce) {
-        if (COUNT) lc.segments++;
-        // alpha walk over the sorted hit list (mod.rs:188-205)
-        Surface surf;
-        MatSample ms;
-        f3 normal = mk3(0.f, 0.f, 0.f);
-        bool have = false;
-        float t_prev = -INFINITY;
-        uint32_t ord_prev = 0;
-        RawHit h;
-        while (next_hit<COUNT>(S, o, d, t_prev, ord_prev, h, lc)) {
-            if (COUNT && have) lc.restarts++;
-            make_surface(S, o, d, h, surf);
-            material_sample(S, surf.model, surf.sphere, surf.uv, ms);
-            normal = shading_normal(S, surf);
-            have = true;
-            if (COUNT) lc.shaded++;
-            float opacity = ms.opacity;
-            if (opacity >= 1.f || (opacity > 0.001f && pt_rng_f32(rng, slab, tid) < opacity)) break;
-            t_prev = h.key;
-            ord_prev = h.ord;
-        }
-        if (!have) return color + mul_ew(thr, ld3(S.background));
-
-        f3 view = -1.f * d;
-        Brdf brdf;
-        ct_init(brdf, ms);
-        color = color + mul_ew(thr, ms.emissive);
-        for (uint32_t li = 0; li < S.n_lights; ++li) {
-            f3 lrad, ldir;
-            light_radiance<COUNT>(S, S.lights[li], surf, lrad, ldir, lc);
-            if (lrad.x == 0.f && lrad.y == 0.f && lrad.z == 0.f) continue;
-            f3 rl = -1.f * ldir;
-            color = color + mul_ew(mul_ew(thr, ct_eval_direct(brdf, normal, view, rl)), lrad);
-        }
-        if (bounce < bounces) {
-            o = surf.pos + surf.normal * 0.00001f;
-            float r1 = pt_rng_f32(rng, slab, tid);
-            float r2 = pt_rng_f32(rng, slab, tid);
-            d = ct_sample(brdf, normal, view, r1, r2);
-            f3 w = ct_eval_indirect(brdf, normal, view, d) / 1.0f;  // / brdf.pdf()
-            thr = mul_ew(thr, w);
-        }
-        if (dot3(thr, thr) < 0.00001f) return color;
-        if (bounce > 3) {  // russian_roulette (utils.rs:23-31)
-            float p = max_rs(max_rs(thr.x, thr.y), thr.z);
-            thr = thr * (1.f / p);
-            if (pt_rng_f32(rng, slab, tid) > p) return color;
-        }
+    PathState ps;
+    path_begin(ps, o, d);
+    while (!path_step<COUNT>(S, bounces, ps, lc, [&]() { return pt_rng_f32(rng, slab, tid); })) {
     }
-    return color;
+    return ps.color;
 }
 
 // Camera ray (mod.rs:107-124)

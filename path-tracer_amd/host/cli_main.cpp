@@ -1,0 +1,205 @@
+// `path-tracer` command line — same surface as the reference binary for the
+// render path (src/main.rs:14-57, src/config/mod.rs:10-52, README.md:28-60):
+//
+//   path-tracer render <INPUT> [-o/--output <OUTPUT>] [-q/--quiet] [-v/--viewer]
+//                              [--debug-textures] [-p/--profile <PROFILE>]
+//       env OUTPUT (default render.png), env PROFILE
+//   path-tracer convert <INPUT> <OUTPUT>      (glTF -> ISF: out of scope)
+//
+// Any error prints the message on stderr and exits with code 2 (main.rs:14-22).
+// The render itself runs on the GPU through the C ABI of include/ptgpu.h;
+// there is no CPU fallback.  Extras (not in the reference): --device N,
+// --stats (prints one JSON line with timings to stderr).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ptgpu.h"
+#include "pthost.h"
+
+namespace {
+
+[[noreturn]] void die(const std::string& msg) {
+    fprintf(stderr, "%s\n", msg.c_str());
+    exit(2);
+}
+
+void usage_render(FILE* f) {
+    fputs("Path-trace awesome things\n\n"
+          "Usage: path-tracer render [OPTIONS] <INPUT>\n\n"
+          "Arguments:\n"
+          "  <INPUT>  Input file name ISF format\n\n"
+          "Options:\n"
+          "  -o, --output <OUTPUT>    Output image name [env: OUTPUT=] [default: render.png]\n"
+          "  -q, --quiet              No progress bar printed\n"
+          "  -v, --viewer             Display a viewer (accepted, ignored on the GPU path)\n"
+          "      --debug-textures     Generate debug textures (not implemented on the GPU path)\n"
+          "  -p, --profile <PROFILE>  A path to the yaml file containing all the rendering profile information [env: PROFILE=]\n"
+          "      --device <N>         HIP device ordinal [default: 0]\n"
+          "      --stats              Print timing statistics as JSON on stderr\n"
+          "  -h, --help               Print help\n",
+          f);
+}
+
+void usage_main(FILE* f) {
+    fputs("Path-trace awesome things\n\n"
+          "Usage: path-tracer <COMMAND>\n\n"
+          "Commands:\n"
+          "  render   Path-trace awesome things\n"
+          "  convert  Convert scenes into ISF format\n"
+          "  help     Print this message or the help of the given subcommand(s)\n\n"
+          "Options:\n"
+          "  -h, --help     Print help\n"
+          "  -V, --version  Print version\n",
+          f);
+}
+
+struct Progress {
+    bool quiet;
+    std::chrono::steady_clock::time_point start;
+};
+
+void on_progress(uint32_t done, uint32_t total, void* user) {
+    Progress* p = (Progress*)user;
+    if (p->quiet) return;
+    int width = 40, filled = total ? (int)((uint64_t)done * width / total) : width;
+    fprintf(stderr, "\rRendering: %u / %u [", done, total);
+    for (int i = 0; i < width; ++i) fputc(i < filled ? '=' : (i == filled ? '>' : '-'), stderr);
+    fprintf(stderr, "] %3u %%", total ? (unsigned)((uint64_t)done * 100 / total) : 100u);
+    fflush(stderr);
+}
+
+int run_render(int argc, char** argv) {
+    std::string input, output, profile_path;
+    bool have_output = false, have_profile = false, quiet = false, debug_textures = false, stats = false;
+    int device = 0;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        auto value = [&](const char* name) -> std::string {
+            size_t eq = a.find('=');
+            if (a.rfind("--", 0) == 0 && eq != std::string::npos) return a.substr(eq + 1);
+            if (i + 1 >= argc) die(std::string("error: a value is required for '") + name + "' but none was supplied");
+            return argv[++i];
+        };
+        if (a == "-h" || a == "--help") {
+            usage_render(stdout);
+            return 0;
+        } else if (a == "-o" || a == "--output" || a.rfind("--output=", 0) == 0) {
+            output = value("--output <OUTPUT>");
+            have_output = true;
+        } else if (a.rfind("-o", 0) == 0 && a.size() > 2 && a[1] == 'o') {
+            output = a.substr(2);
+            have_output = true;
+        } else if (a == "-p" || a == "--profile" || a.rfind("--profile=", 0) == 0) {
+            profile_path = value("--profile <PROFILE>");
+            have_profile = true;
+        } else if (a.rfind("-p", 0) == 0 && a.size() > 2 && a[1] == 'p') {
+            profile_path = a.substr(2);
+            have_profile = true;
+        } else if (a == "-q" || a == "--quiet") quiet = true;
+        else if (a == "-v" || a == "--viewer") {
+            // accepted and ignored: no window system on a headless GPU node
+        } else if (a == "-qv" || a == "-vq") quiet = true;
+        else if (a == "--debug-textures") debug_textures = true;
+        else if (a == "--stats") stats = true;
+        else if (a == "--device" || a.rfind("--device=", 0) == 0) device = atoi(value("--device <N>").c_str());
+        else if (a.size() > 1 && a[0] == '-' && a != "-")
+            die("error: unexpected argument '" + a + "' found\n\nUsage: path-tracer render [OPTIONS] <INPUT>");
+        else if (input.empty()) input = a;
+        else die("error: unexpected argument '" + a + "' found\n\nUsage: path-tracer render [OPTIONS] <INPUT>");
+    }
+    if (input.empty()) die("error: the following required arguments were not provided:\n  <INPUT>\n\nUsage: path-tracer render [OPTIONS] <INPUT>");
+    if (!have_output) {
+        const char* e = getenv("OUTPUT");
+        output = e && *e ? e : "render.png";
+    }
+    if (!have_profile) {
+        const char* e = getenv("PROFILE");
+        if (e && *e) {
+            profile_path = e;
+            have_profile = true;
+        }
+    }
+    if (debug_textures) die("--debug-textures is not implemented on the GPU path (SURVEY §8-f2)");
+
+    // Profile::load / Default (main.rs:33-36)
+    pt_profile profile;
+    if (pth_profile_load(have_profile ? profile_path.c_str() : nullptr, &profile) != PT_OK) die(pth_last_error());
+
+    auto t0 = std::chrono::steady_clock::now();
+    pth_scene* hscene = nullptr;  // load_internal (main.rs:38)
+    if (pth_scene_load_isf(input.c_str(), &hscene) != PT_OK) die(pth_last_error());
+    auto t1 = std::chrono::steady_clock::now();
+
+    pt_scene* scene = nullptr;
+    if (pt_scene_create(pth_scene_desc(hscene), device, &scene) != PT_OK) die(pt_last_error());
+    auto t2 = std::chrono::steady_clock::now();
+
+    // Renderer::new + render (main.rs:46-47)
+    Progress prog{quiet, std::chrono::steady_clock::now()};
+    pt_opts opts;
+    memset(&opts, 0, sizeof opts);
+    opts.device = device;
+    opts.flags = PT_FLAG_TIMING;
+    if (!quiet) {
+        opts.progress = on_progress;
+        opts.progress_user = &prog;
+        opts.sample_batch = profile.samples > 16 ? (profile.samples + 15) / 16 : 1;  // ~16 progress ticks
+    }
+    std::vector<uint8_t> rgb((size_t)profile.width * profile.height * 3);
+    if (pt_render(scene, &profile, &opts, rgb.data(), nullptr) != PT_OK) die(pt_last_error());
+    auto t3 = std::chrono::steady_clock::now();
+    if (!quiet)
+        fprintf(stderr, "\nDone: %llds\n", (long long)std::chrono::duration_cast<std::chrono::seconds>(t3 - t2).count());
+
+    // rendered_image.save(output) (main.rs:50); the format follows the extension, PNG only here
+    size_t dot = output.find_last_of('.');
+    std::string ext = dot == std::string::npos ? "" : output.substr(dot + 1);
+    for (char& c : ext) c = (char)tolower(c);
+    if (ext != "png") die("The image format could not be determined (only .png output is supported): " + output);
+    if (pth_png_write_rgb8(output.c_str(), profile.width, profile.height, rgb.data()) != PT_OK) die(pth_last_error());
+    auto t4 = std::chrono::steady_clock::now();
+
+    if (stats) {
+        pt_timing tm{};
+        pt_scene_info info{};
+        pt_get_timing(scene, &tm);
+        pt_scene_get_info(scene, &info);
+        auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+        double samples = (double)profile.width * profile.height * profile.samples;
+        fprintf(stderr,
+                "{\"load_s\": %.3f, \"kd_build_s\": %.3f, \"upload_s\": %.3f, \"render_s\": %.3f, \"kernel_ms\": %.3f, "
+                "\"png_s\": %.3f, \"msamples_per_s\": %.2f, \"prims\": %llu, \"kd_nodes\": %llu, \"leaf_refs\": %llu}\n",
+                sec(t0, t1), (double)info.kd_build_seconds, (double)info.upload_seconds, sec(t2, t3),
+                (double)tm.integrate_ms, sec(t3, t4), samples / sec(t2, t3) / 1e6, (unsigned long long)info.n_prims,
+                (unsigned long long)info.n_kd_nodes, (unsigned long long)info.n_leaf_refs);
+    }
+    pt_scene_destroy(scene);
+    pth_scene_free(hscene);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        usage_main(stderr);
+        return 2;
+    }
+    std::string cmd = argv[1];
+    if (cmd == "render") return run_render(argc - 2, argv + 2);
+    if (cmd == "convert") die("convert (glTF -> ISF) is outside the scope of this build: the render path consumes ISF "
+                              "files produced by the reference's converter (SURVEY §2 row 14)");
+    if (cmd == "-h" || cmd == "--help" || cmd == "help") {
+        usage_main(stdout);
+        return 0;
+    }
+    if (cmd == "-V" || cmd == "--version") {
+        printf("path-tracer 0.1.0 (%s)\n", pt_version());
+        return 0;
+    }
+    die("error: unrecognized subcommand '" + cmd + "'\n\nUsage: path-tracer <COMMAND>");
+}

@@ -101,8 +101,7 @@ struct Builder {
         std::vector<Edge> edges(2 * n);
         float best_split = 0.f;
         bool best_planar_below = true;
-        int axis = d[0] > d[1] ? (d[0] > d[2] ? 0 : 2) : (d[1] > d[2] ? 1 : 2);
-        for (int retry = 0; retry < 3; ++retry, axis = (axis + 1) % 3) {
+        for (int axis = 0; axis < 3; ++axis) {  // full SAH: best plane over all three axes
             if (!(d[axis] > 0.f)) continue;  // flat box: nothing to cut on this axis
             const float lo = nb.mn[axis], hi = nb.mx[axis];
             for (size_t i = 0; i < n; ++i) {
@@ -158,7 +157,6 @@ struct Builder {
                 n_below += starts;
                 i = j;
             }
-            if (best_axis != -1) break;  // otherwise: no usable plane on this axis, try the next
         }
         if (best_cost > old_cost) ++bad;
         // small nodes stop as soon as splitting no longer pays (Wald's automatic

@@ -1,0 +1,51 @@
+"""`path-tracer` CLI surface (src/config/mod.rs:20-52, src/main.rs:14-57): flags, env, exit code 2."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT, SCENES
+
+EXE = ROOT / "path-tracer_amd" / "path-tracer"
+
+
+def run(*args, env=None):
+    return subprocess.run([str(EXE), *args], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+
+
+def test_cli_exists_and_prints_help():
+    assert EXE.exists(), "run `make cli`"
+    r = run("render", "--help")
+    assert r.returncode == 0
+    for flag in ("--output", "--quiet", "--viewer", "--debug-textures", "--profile", "OUTPUT", "PROFILE", "render.png"):
+        assert flag in r.stdout
+    assert run("--help").returncode == 0 and "convert" in run("--help").stdout
+
+
+@pytest.mark.parametrize("args", [(), ("render",), ("render", "/no/such/scene.isf", "-q"), ("bogus",),
+                                  ("render", "a.isf", "--nope"), ("convert", "a.glb", "out/"),
+                                  ("render", str(SCENES / "cube" / "scene.isf"), "-q", "-p", "/no/such/profile.yml")])
+def test_cli_errors_exit_with_code_2(args):
+    r = run(*args)
+    assert r.returncode == 2
+    assert r.stderr.strip()
+
+
+def test_cli_bad_profile_and_env(tmp_path):
+    bad = tmp_path / "bad.yml"
+    bad.write_text("tonemap: PURPLE\n")
+    r = run("render", str(SCENES / "cube" / "scene.isf"), "-q", env={"PROFILE": str(bad)})
+    assert r.returncode == 2 and "PURPLE" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_renders_like_the_library(tmp_path, pta, gpu_scene_cache):
+    import numpy as np
+    from PIL import Image
+    prof = tmp_path / "p.yml"
+    prof.write_text("resolution:\n  width: 96\n  height: 64\nsamples: 4\nbounces: 2\n")
+    out = tmp_path / "o.png"
+    r = run("render", str(SCENES / "reflection" / "scene.isf"), "-q", "-p", str(prof), env={"OUTPUT": str(out)})
+    assert r.returncode == 0, r.stderr
+    rgb, _ = gpu_scene_cache("reflection").render(pta.Profile.make(96, 64, 4, 2))
+    assert np.array_equal(np.asarray(Image.open(out)).reshape(-1, 3), rgb)

@@ -1,0 +1,225 @@
+"""Host side that 'stays' around the hot path: ISF loader (serde defaults of src/scene/isf.rs),
+PNG codec (image crate stand-in), profile.yml parser (src/config/profile.rs), scene generator."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+TRI = [{"position": [0, 0, 0], "normal": [0, 0, 1], "tex_coords": [0, 0]},
+       {"position": [1, 0, 0], "normal": [0, 0, 1], "tex_coords": [1, 0]},
+       {"position": [0, 1, 0], "normal": [0, 0, 1], "tex_coords": [0, 1]}]
+CAMERA = {"transform": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 5, 1]], "fov": 0.7, "zfar": 100.0, "znear": 0.1}
+
+
+def write_scene(tmp_path, models, lights=(), background=(0.1, 0.2, 0.3), **extra):
+    doc = {"models": models, "camera": CAMERA, "lights": list(lights), "background": list(background)}
+    doc.update(extra)
+    p = tmp_path / "scene.isf"
+    p.write_text(json.dumps(doc))
+    return p
+
+
+def test_material_serde_defaults(pta, tmp_path):
+    """isf.rs:83-138: missing emissive -> [0,0,0]; emissive without factor -> [1,1,1]; missing metalness -> 0,
+    present without factor -> 1; missing opacity/roughness -> 1; ior default 1; albedo factor default [1,1,1]."""
+    models = [
+        {"type": "Mesh", "triangles": [TRI], "material": {"albedo": {}}},
+        {"type": "Mesh", "triangles": [TRI, TRI], "material": {"albedo": {"factor": [0.5, 0.25, 0.125]}, "emissive": {},
+                                                             "metalness": {}, "opacity": {"factor": 0.5},
+                                                             "roughness": {"factor": 0.25}, "ior": 1.5,
+                                                             "unknown_key": {"nested": [1, 2, {"x": None}]}}},
+        {"material": {"albedo": {"factor": [1, 1, 1], "texture": None}, "normal_texture": None},
+         "center": [1, 2, 3], "radius": 2.5, "type": "Sphere"},  # tag after the other keys
+    ]
+    s = pta.HostScene.load_isf(write_scene(tmp_path, models, ignored_top_level=[1, 2, 3]))
+    d = s.desc.contents
+    assert (d.n_models, d.n_materials, d.n_triangles, s.n_prims) == (3, 3, 3, 4)
+    m0, m1, m2 = d.materials[0], d.materials[1], d.materials[2]
+    assert list(m0.albedo) == [1, 1, 1] and list(m0.emissive) == [0, 0, 0]
+    assert (m0.opacity, m0.metalness, m0.roughness, m0.ior) == (1, 0, 1, 1)
+    assert list(m1.albedo) == [0.5, 0.25, 0.125] and list(m1.emissive) == [1, 1, 1]
+    assert (m1.opacity, m1.metalness, m1.roughness, m1.ior) == (0.5, 1, 0.25, 1.5)
+    assert all(t == -1 for t in (m0.tex_albedo, m0.tex_emissive, m0.tex_opacity, m0.tex_metalness, m0.tex_roughness, m0.tex_normal))
+    assert d.models[1].tri_first == 1 and d.models[1].tri_count == 2
+    assert d.models[2].kind == pta.PT_MODEL_SPHERE and d.models[2].radius == 2.5 and list(d.models[2].center) == [1, 2, 3]
+    assert list(d.background) == pytest.approx([0.1, 0.2, 0.3])
+    assert list(d.camera.transform)[12:15] == [0, 0, 5]
+
+
+def test_f32_values_go_through_f64(pta, tmp_path):
+    tri = json.loads(json.dumps(TRI))
+    tri[0]["position"] = [0.24095196, 1e-45, 16777217.0]
+    s = pta.HostScene.load_isf(write_scene(tmp_path, [{"type": "Mesh", "triangles": [tri], "material": {"albedo": {}}}]))
+    got = np.ctypeslib.as_array(s.desc.contents.triangles, (24,))[:3]
+    assert np.array_equal(got, np.array([0.24095196, 1e-45, 16777217.0], np.float64).astype(np.float32))
+
+
+@pytest.mark.parametrize("mutate,needle", [
+    (lambda d: d.pop("lights"), "lights"),
+    (lambda d: d.pop("background"), "background"),
+    (lambda d: d["models"][0].pop("material"), "material"),
+    (lambda d: d["models"][0]["material"].pop("albedo"), "albedo"),
+    (lambda d: d["models"][0].__setitem__("type", "Cube"), "Cube"),
+    (lambda d: d["models"][0]["triangles"][0][0].pop("normal"), "normal"),
+    (lambda d: d["camera"].pop("fov"), "fov"),
+])
+def test_loader_errors(pta, tmp_path, mutate, needle):
+    doc = {"models": [{"type": "Mesh", "triangles": [json.loads(json.dumps(TRI))], "material": {"albedo": {}}}],
+           "camera": dict(CAMERA), "lights": [], "background": [0, 0, 0]}
+    mutate(doc)
+    p = tmp_path / "bad.isf"
+    p.write_text(json.dumps(doc))
+    with pytest.raises(pta.PtError) as e:
+        pta.HostScene.load_isf(p)
+    assert needle in str(e.value)
+
+
+def test_loader_syntax_and_io_errors(pta, tmp_path):
+    p = tmp_path / "broken.isf"
+    p.write_text('{"models": [')
+    with pytest.raises(pta.PtError):
+        pta.HostScene.load_isf(p)
+    with pytest.raises(pta.PtError):
+        pta.HostScene.load_isf(tmp_path / "missing.isf")
+    q = write_scene(tmp_path, [{"type": "Mesh", "triangles": [TRI], "material": {"albedo": {"texture": "nope.png"}}}])
+    with pytest.raises(pta.PtError) as e:
+        pta.HostScene.load_isf(q)
+    assert "Invalid path" in str(e.value)  # texture_bank.rs:26
+
+
+def test_reference_scenes_load(pta, scene_cache):
+    expect = {"cube": (1, 12), "reflection": (2, 1932), "head": (1, 2492), "spheres": (25, 0),
+              "alpha_transparency": (8, 56), "white_furnace_indirect": (25, 0), "white_furnace_direct": (9, 108)}
+    for name, (n_models, n_tris) in expect.items():
+        d = scene_cache(name).desc.contents
+        assert (d.n_models, d.n_triangles) == (n_models, n_tris), name
+    head = scene_cache("head").desc.contents
+    assert head.n_textures == 2 and head.n_lights == 2
+    assert (head.textures[0].width, head.textures[0].height, head.textures[0].channels) == (1024, 1024, 3)
+    assert head.textures[1].channels == 1
+
+
+def test_png_decode_matches_pil(pta):
+    from PIL import Image
+    for rel, ch in (("head/albedo_tex_0.png", 3), ("head/alpha_tex_0.png", 1), ("alpha_transparency/albedo_tex_0.png", 3),
+                    ("head/albedo_tex_0.png", 1)):
+        w, h, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+        path = SCENES / rel
+        pta.check_host(pta.host_lib().pth_png_read(str(path).encode(), ch, C.byref(w), C.byref(h), C.byref(px)))
+        got = np.ctypeslib.as_array(px, (h.value, w.value, ch)).copy()
+        pta.host_lib().pth_free(px)
+        img = Image.open(path)
+        if ch == 3:
+            ref = np.asarray(img.convert("RGB"))
+            assert np.array_equal(got, ref), rel
+        elif img.mode in ("L", "P", "1"):
+            assert np.array_equal(got[..., 0], np.asarray(img.convert("L"))), rel
+        else:  # image 0.25 rgb -> luma: (2126 r + 7152 g + 722 b) / 10000
+            rgb = np.asarray(img.convert("RGB")).astype(np.uint32)
+            ref = ((2126 * rgb[..., 0] + 7152 * rgb[..., 1] + 722 * rgb[..., 2]) // 10000).astype(np.uint8)
+            assert np.array_equal(got[..., 0], ref), rel
+
+
+def test_png_write_read_round_trip(pta, tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    path = tmp_path / "rt.png"
+    pta.check_host(pta.host_lib().pth_png_write_rgb8(str(path).encode(), 53, 37, img.ctypes.data))
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(path)), img)
+    w, h, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+    pta.check_host(pta.host_lib().pth_png_read(str(path).encode(), 3, C.byref(w), C.byref(h), C.byref(px)))
+    assert np.array_equal(np.ctypeslib.as_array(px, (37, 53, 3)), img)
+    pta.host_lib().pth_free(px)
+
+
+def test_png_other_formats_via_pil(pta, tmp_path):
+    """Palette, grey+alpha, RGBA, 16-bit and sub-byte PNGs decode like `image` (unpinned by the reference)."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (9, 11, 3), dtype=np.uint8)
+    cases = {"p.png": Image.fromarray(rgb).quantize(16), "la.png": Image.fromarray(rgb).convert("LA"),
+             "rgba.png": Image.fromarray(rgb).convert("RGBA"), "one.png": Image.fromarray(rgb).convert("1")}
+    for name, im in cases.items():
+        im.save(tmp_path / name)
+        w, h, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+        pta.check_host(pta.host_lib().pth_png_read(str(tmp_path / name).encode(), 3, C.byref(w), C.byref(h), C.byref(px)))
+        got = np.ctypeslib.as_array(px, (9, 11, 3)).copy()
+        pta.host_lib().pth_free(px)
+        assert np.array_equal(got, np.asarray(im.convert("RGB"))), name
+
+
+def test_texture_cache_and_sharing(pta, tmp_path):
+    from PIL import Image
+    Image.fromarray(np.full((4, 4, 3), 200, np.uint8)).save(tmp_path / "t.png")
+    mat = {"albedo": {"texture": "t.png"}, "opacity": {"texture": "./t.png"}, "emissive": {"texture": "t.png"}}
+    s = pta.HostScene.load_isf(write_scene(tmp_path, [{"type": "Mesh", "triangles": [TRI], "material": mat},
+                                                      {"type": "Mesh", "triangles": [TRI], "material": mat}]))
+    d = s.desc.contents
+    assert d.n_textures == 2  # one rgb + one luma entry for the same canonical path (texture_bank.rs)
+    assert d.materials[0].tex_albedo == d.materials[1].tex_albedo == d.materials[0].tex_emissive
+    assert d.materials[0].tex_opacity == d.materials[1].tex_opacity != d.materials[0].tex_albedo
+    tex = d.textures[d.materials[0].tex_opacity]
+    assert tex.channels == 1 and d.texels[tex.offset] == 200
+
+
+# ----------------------------------------------------------------------------- profile.yml
+def test_profile_defaults(pta):
+    p = pta.load_profile(None)
+    assert (p.width, p.height, p.samples, p.bounces, p.brdf, p.tonemap) == (1920, 1080, 64, 4, 0, pta.PT_TONEMAP_FILMIC)
+    p = pta.load_profile(text="")
+    assert (p.width, p.height, p.samples, p.bounces) == (1920, 1080, 64, 4)
+
+
+def test_profile_readme_example(pta):
+    text = """resolution: # Resolution of the output image
+  width: 1280
+  height: 720
+samples: 128 # Number of sample ray throw by pixel
+bounces: 5 # Maximum number of bounces per sample
+brdf: COOK_TORRANCE # Which brdf to use
+tonemap: ACES # Which color tone map to use
+"""
+    p = pta.load_profile(text=text)
+    assert (p.width, p.height, p.samples, p.bounces, p.tonemap) == (1280, 720, 128, 5, pta.PT_TONEMAP_ACES)
+
+
+def test_profile_variants(pta, tmp_path):
+    p = pta.load_profile(text="---\nresolution: {width: 800, height: 600}\ntonemap: 'REINHARD'\nunknown: 3\nother:\n  nested: 1\n")
+    assert (p.width, p.height, p.tonemap, p.samples) == (800, 600, pta.PT_TONEMAP_REINHARD, 64)
+    f = tmp_path / "p.yml"
+    f.write_text("samples: 7\n")
+    assert pta.load_profile(f).samples == 7
+    for bad in ("resolution:\n  width: 5\n", "tonemap: BLUE\n", "samples: -3\n", "brdf: PHONG\n", "samples: many\n"):
+        with pytest.raises(pta.PtError):
+            pta.load_profile(text=bad)
+    with pytest.raises(pta.PtError):
+        pta.load_profile(tmp_path / "missing.yml")
+
+
+# ----------------------------------------------------------------------------- generator
+def test_generator_is_deterministic_and_round_trips(pta, tmp_path):
+    a = pta.HostScene.generate_ps5(6000, 0)
+    b = pta.HostScene.generate_ps5(6000, 0)
+    c = pta.HostScene.generate_ps5(6000, 1)
+    n = a.n_triangles
+    assert 0.8 * 6000 <= n <= 1.2 * 6000
+    ta = np.ctypeslib.as_array(a.desc.contents.triangles, (n * 24,))
+    assert np.array_equal(ta, np.ctypeslib.as_array(b.desc.contents.triangles, (n * 24,)))
+    assert not np.array_equal(ta, np.ctypeslib.as_array(c.desc.contents.triangles, (c.n_triangles * 24,))[: n * 24])
+    a.save_isf(tmp_path / "gen")
+    r = pta.HostScene.load_isf(tmp_path / "gen" / "scene.isf")
+    assert r.n_triangles == n
+    assert np.array_equal(ta.view(np.uint32), np.ctypeslib.as_array(r.desc.contents.triangles, (n * 24,)).view(np.uint32))
+    for i in range(a.desc.contents.n_materials):
+        ma, mr = a.desc.contents.materials[i], r.desc.contents.materials[i]
+        assert bytes(ma)[:40] == bytes(mr)[:40]
+    t = pta.HostScene.generate_ps5(3000, 0, flags=1)  # translucent shells + checker opacity texture
+    assert t.desc.contents.n_textures == 1 and t.desc.contents.textures[0].channels == 1
+    t.save_isf(tmp_path / "gen_alpha")
+    rt = pta.HostScene.load_isf(tmp_path / "gen_alpha" / "scene.isf")
+    nt = int(rt.desc.contents.n_texel_bytes)
+    assert np.array_equal(np.ctypeslib.as_array(t.desc.contents.texels, (nt,)), np.ctypeslib.as_array(rt.desc.contents.texels, (nt,)))
