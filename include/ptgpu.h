@@ -214,10 +214,17 @@ int pt_assemble_tiles(const pt_profile* profile, uint32_t shard_count, uint32_t 
 /* ------------------------------------------------------------------ */
 
 typedef struct pt_timing {
-    uint32_t launches;        /* integrator kernel launches in the last render */
-    float integrate_ms;       /* sum of their HIP-event durations             */
-    float postprocess_ms;     /* tone-map kernel                               */
-    float total_ms;           /* first launch -> last kernel done              */
+    uint32_t launches;        /* launches of the dominant kernel in the last render
+                                 (k_wf_trace for the wavefront integrator)         */
+    float integrate_ms;       /* sum of their HIP-event durations                  */
+    float postprocess_ms;     /* tone-map kernel                                   */
+    float total_ms;           /* first launch -> last kernel done                  */
+    float generate_ms;        /* per-stage sums (wavefront integrator)             */
+    float trace_ms;
+    float shade_ms;
+    float shadow_ms;
+    float accumulate_ms;
+    uint32_t stage_launches;  /* all integrator launches                           */
 } pt_timing;
 
 /* Exact work counters from the instrumented variant (PT_FLAG_COUNTERS);
@@ -231,6 +238,8 @@ typedef struct pt_counters {
     uint64_t shaded_hits;     /* material fetches (H)                  */
     uint64_t rng_draws;
     uint64_t restarts;        /* alpha-walk continuation casts         */
+    uint64_t max_nodes_per_cast;   /* longest single KD walk (wavefront integrator) */
+    uint64_t casts_over_1k_nodes;
 } pt_counters;
 
 int pt_get_timing(const pt_scene* scene, pt_timing* out);

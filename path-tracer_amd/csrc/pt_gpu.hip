@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "pt_integrator.h"
+#include "pt_wavefront.h"
 #include "pthost.h"
 
 // ------------------------------------------------------------------ errors
@@ -148,39 +149,6 @@ __global__ __launch_bounds__(256) void k_render(DevScene S, RenderParams P, cons
 // block64 enumerates the 8x8 pixel blocks of this call's tiles, so 64 consecutive items are one
 // coherent 8x8 block of primary rays of the same sample, and consecutive groups are the next
 // samples of the same block (the CUs stay on one image region: better L2 locality per XCD).
-struct ItemRef {
-    uint32_t x, y, global_index, out_index, sample;  // sample is 1-based (mod.rs:105)
-    bool valid;
-};
-
-__device__ __forceinline__ ItemRef decode_item(const RenderParams& P, const uint32_t* __restrict__ tile_offsets,
-                                               uint32_t item) {
-    ItemRef r;
-    uint32_t batch = P.sample_end - P.sample_begin;
-    uint32_t lane = item & 63u;
-    uint32_t g = item >> 6;
-    uint32_t s_rel = g % batch, b64 = g / batch;
-    uint32_t blocks_per_tile = (P.tile_w >> 3) * (P.tile_h >> 3);
-    uint32_t lt = b64 / blocks_per_tile, sub = b64 % blocks_per_tile;
-    uint32_t waves_x = P.tile_w >> 3;
-    uint32_t tx = (sub % waves_x) * 8u + (lane & 7u);
-    uint32_t ty = (sub / waves_x) * 8u + (lane >> 3);
-    uint32_t k = P.shard_rank + lt * P.shard_count;
-    uint32_t tile_x = k % P.tiles_x, tile_y = k / P.tiles_x;
-    r.x = tile_x * P.tile_w + tx;
-    r.y = tile_y * P.tile_h + ty;
-    r.valid = tile_y < P.tiles_y && r.x < P.width && r.y < P.height;
-    r.global_index = r.x + r.y * P.width;
-    r.sample = P.sample_begin + 1u + s_rel;
-    if (P.shard_count <= 1) {
-        r.out_index = r.global_index;
-    } else {
-        uint32_t cw = min(P.tile_w, P.width - tile_x * P.tile_w);
-        r.out_index = tile_offsets[lt] + ty * cw + tx;
-    }
-    return r;
-}
-
 // First ChaCha12 block of every work item, word-major ([16][n_items]) so that the lanes of
 // a wavefront store 16 coalesced rows.  A fully converged kernel: ~700 integer ops per item.
 __global__ __launch_bounds__(256) void k_rng_blocks(RenderParams P, const uint32_t* __restrict__ tile_offsets,
@@ -504,7 +472,8 @@ struct pt_scene {
     mutable pt_timing timing{};
     mutable pt_counters counters{};
     mutable DeviceBuffer accum_scratch, tile_table, counter_buf, staging_buf, rng_buf, work_counter;
-    mutable int persist_blocks = 0;
+    mutable DeviceBuffer wf_queue[2], wf_hits, wf_shadow, wf_contrib, wf_ctr;
+    mutable int persist_blocks = 0, trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
     mutable std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> tile_key{0, 0, 0, 0, 0, 0};
     mutable std::vector<hipEvent_t> events;
 
@@ -724,79 +693,192 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     P.tiles_y = tm.tiles_y;
     P.n_local = (uint32_t)tm.n_local;
 
-    // ---- choose the integrator: persistent with path regeneration (default) or the plain
-    // one-lane-per-pixel megakernel (PT_INTEGRATOR=mega, kept for A/B measurements)
-    static const bool use_mega = [] {
+    // ---- integrator selection: wavefront (default), or for A/B measurements the fused
+    // persistent kernel (PT_INTEGRATOR=persist) / the one-lane-per-pixel megakernel (=mega)
+    static const int mode = [] {
         const char* e = getenv("PT_INTEGRATOR");
-        return e && !strcmp(e, "mega");
+        if (e && !strcmp(e, "mega")) return 0;
+        if (e && !strcmp(e, "persist")) return 1;
+        return 2;
     }();
     const uint32_t blocks64 = tm.n_local_tiles * (o.tile_w / 8u) * (o.tile_h / 8u);
-    // staging: 12 B radiance + 64 B RNG block per work item; default budget 32 GiB of the 288 GB
+    // staging budget (radiance 12 B + RNG block 64 B per work item [+ queues]); default 32 GiB of 288 GB
     static const uint64_t budget = [] {
         const char* e = getenv("PT_STAGING_GIB");
         return (uint64_t)((e && *e ? atof(e) : 32.0) * 1024.0 * 1024.0 * 1024.0);
     }();
+    static const uint32_t wf_cap = [] {
+        const char* e = getenv("PT_WF_CHUNK");
+        return (uint32_t)(e && *e ? atof(e) : 128.0 * 1024 * 1024);
+    }();
+    static const uint32_t wf_refill = [] {
+        const char* e = getenv("PT_WF_REFILL");
+        return (uint32_t)(e && *e ? atoi(e) : 16);
+    }();
+    static const uint32_t wf_walk = [] {
+        const char* e = getenv("PT_WF_WALK");
+        return (uint32_t)(e && *e ? atoi(e) : 12);
+    }();
+    if (s.n_cu == 0) HIP_CHECK(hipDeviceGetAttribute(&s.n_cu, hipDeviceAttributeMultiprocessorCount, s.device));
     uint32_t batch = o.sample_batch ? o.sample_batch : p.samples;
-    if (!use_mega) {
-        uint64_t per_sample = (uint64_t)blocks64 * 64u * 64u + tm.n_local * 12u;
+    const bool alpha = s.dev.has_translucent != 0;
+    if (mode >= 1) {
+        uint64_t per_sample = (mode == 1 ? (uint64_t)blocks64 * 64u * 64u : 0) + tm.n_local * 12u;
         uint64_t max_batch = std::max<uint64_t>(1, budget / std::max<uint64_t>(1, per_sample));
         max_batch = std::min<uint64_t>(max_batch, 0x7fffffffull / ((uint64_t)blocks64 * 64u));
         if (max_batch == 0) fail(PT_ERR_UNSUPPORTED, "image too large for one sample batch");
         batch = (uint32_t)std::min<uint64_t>(batch, max_batch);
-        if (s.persist_blocks == 0) {
-            int per_cu = 0, n_cu = 0;
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_persist<false>, 256, 0));
-            HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s.device));
-            s.persist_blocks = std::max(1, per_cu) * std::max(1, n_cu);
-        }
         s.staging_buf.ensure((size_t)batch * tm.n_local * 12);
-        s.rng_buf.ensure((size_t)batch * blocks64 * 64u * 64u);
         s.work_counter.ensure(256);
+    }
+    if (mode == 1) {
+        if (s.persist_blocks == 0) {
+            int per_cu = 0;
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_persist<false>, 256, 0));
+            s.persist_blocks = std::max(1, per_cu) * std::max(1, s.n_cu);
+        }
+        s.rng_buf.ensure((size_t)batch * blocks64 * 64u * 64u);
+    }
+    uint32_t cap = 0;
+    if (mode == 2) {
+        uint64_t items_per_batch = (uint64_t)blocks64 * 64u * batch;
+        // chunks are whole 64-item groups
+        cap = (uint32_t)std::min<uint64_t>(items_per_batch, std::max<uint32_t>(64u, wf_cap & ~63u));
+        if (s.trace_blocks == 0) {
+            int a = 0, b = 0, c = 0, d = 0;
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_wf_trace<false, false>, 256, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_wf_trace<true, false>, 256, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_wf_shadow<false, false>, 256, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, k_wf_shadow<true, false>, 256, 0));
+            s.trace_blocks = std::max(1, alpha ? b : a) * s.n_cu;
+            s.shadow_blocks = std::max(1, alpha ? d : c) * s.n_cu;
+        }
+        s.rng_buf.ensure((size_t)cap * 64u);
+        s.wf_queue[0].ensure((size_t)cap * 64u);
+        s.wf_queue[1].ensure((size_t)cap * 64u);
+        s.wf_hits.ensure((size_t)cap * 16u);
+        s.wf_shadow.ensure((size_t)cap * 64u);
+        s.wf_contrib.ensure((size_t)cap * 16u * std::max(1u, s.dev.n_lights));
+        s.wf_ctr.ensure(sizeof(WfCounters) * (p.bounces + 3));
     }
     uint32_t blocks = tm.n_local_tiles * (o.tile_w * o.tile_h / 256u);
     size_t ev = 0;
-    uint32_t launches = 0;
+    uint32_t launches = 0, stage_launches = 0;
+    // (stage id, first event index) of every timed launch: 0 generate 1 trace 2 shade 3 shadow 4 accumulate 5 fused
+    std::vector<std::pair<int, size_t>> marks;
+    auto stage_begin = [&](int stage) {
+        if (!timing) return;
+        marks.emplace_back(stage, ev);
+        HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+    };
+    auto stage_end = [&]() {
+        ++stage_launches;
+        if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+    };
+    DevCounters* gctr = counting ? (DevCounters*)s.counter_buf.p : nullptr;
     for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
         P.sample_begin = s0;
         P.sample_end = std::min(p.samples, s0 + batch);
-        if (use_mega) {
-            if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+        uint32_t nb = P.sample_end - P.sample_begin;
+        if (mode == 0) {
+            stage_begin(5);
             if (counting)
-                hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum,
-                                   (DevCounters*)s.counter_buf.p);
+                hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum, gctr);
             else
-                hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum,
-                                   (DevCounters*)nullptr);
+                hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum, gctr);
             HIP_CHECK(hipGetLastError());
-            if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
-        } else {
-            uint32_t nb = P.sample_end - P.sample_begin;
+            stage_end();
+            ++launches;
+        } else if (mode == 1) {
             uint32_t n_items = blocks64 * 64u * nb;
+            stage_begin(0);
             hipLaunchKernelGGL(k_rng_blocks, dim3((n_items + 255u) / 256u), dim3(256), 0, stream, P, d_tiles, n_items,
                                (uint32_t*)s.rng_buf.p);
             HIP_CHECK(hipGetLastError());
+            stage_end();
             HIP_CHECK(hipMemsetAsync(s.work_counter.p, 0, 4, stream));
-            if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+            stage_begin(5);
             if (counting)
                 hipLaunchKernelGGL(k_render_persist<true>, dim3(s.persist_blocks), dim3(256), 0, stream, s.dev, P, d_tiles,
                                    (const uint32_t*)s.rng_buf.p, n_items, (float*)s.staging_buf.p,
-                                   (uint32_t*)s.work_counter.p, (DevCounters*)s.counter_buf.p);
+                                   (uint32_t*)s.work_counter.p, gctr);
             else
                 hipLaunchKernelGGL(k_render_persist<false>, dim3(s.persist_blocks), dim3(256), 0, stream, s.dev, P, d_tiles,
                                    (const uint32_t*)s.rng_buf.p, n_items, (float*)s.staging_buf.p,
-                                   (uint32_t*)s.work_counter.p, (DevCounters*)nullptr);
+                                   (uint32_t*)s.work_counter.p, gctr);
             HIP_CHECK(hipGetLastError());
-            if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+            stage_end();
+            ++launches;
+        } else {
+            uint32_t total_items = blocks64 * 64u * nb;
+            for (uint32_t base = 0; base < total_items; base += cap) {
+                WfParams W{};
+                W.P = P;
+                W.item_base = base;
+                W.n_items = std::min(cap, total_items - base);
+                W.cap = cap;
+                W.refill_min = std::max(1u, std::min(64u, wf_refill));
+                W.walk_steps = std::max(1u, wf_walk);
+                WfCounters* wctr = (WfCounters*)s.wf_ctr.p;
+                HIP_CHECK(hipMemsetAsync(wctr, 0, sizeof(WfCounters) * (p.bounces + 3), stream));
+                stage_begin(0);
+                hipLaunchKernelGGL(k_wf_generate, dim3((W.n_items + 255u) / 256u), dim3(256), 0, stream, s.dev, W, d_tiles,
+                                   (uint32_t*)s.rng_buf.p, (float4*)s.wf_queue[0].p, wctr, gctr);
+                HIP_CHECK(hipGetLastError());
+                stage_end();
+                for (uint32_t b = 0; b <= p.bounces; ++b) {
+                    W.bounce = b;
+                    float4* q_in = (float4*)s.wf_queue[b & 1].p;
+                    float4* q_out = (float4*)s.wf_queue[(b + 1) & 1].p;
+                    const uint32_t* rngb = (const uint32_t*)s.rng_buf.p;
+#define PT_LAUNCH_AC(kernel, grid, ...)                                                                         \
+    do {                                                                                                        \
+        if (alpha && counting) hipLaunchKernelGGL((kernel<true, true>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);    \
+        else if (alpha) hipLaunchKernelGGL((kernel<true, false>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);          \
+        else if (counting) hipLaunchKernelGGL((kernel<false, true>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((kernel<false, false>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                    \
+        HIP_CHECK(hipGetLastError());                                                                           \
+    } while (0)
+#define PT_LAUNCH_SHADE(kernel, grid, ...)                                                                      \
+    do {                                                                                                        \
+        if (alpha && counting) hipLaunchKernelGGL((kernel<true, true>), dim3(grid), dim3(WF_SHADE_THREADS), 0, stream, __VA_ARGS__); \
+        else if (alpha) hipLaunchKernelGGL((kernel<true, false>), dim3(grid), dim3(WF_SHADE_THREADS), 0, stream, __VA_ARGS__);       \
+        else if (counting) hipLaunchKernelGGL((kernel<false, true>), dim3(grid), dim3(WF_SHADE_THREADS), 0, stream, __VA_ARGS__);    \
+        else hipLaunchKernelGGL((kernel<false, false>), dim3(grid), dim3(WF_SHADE_THREADS), 0, stream, __VA_ARGS__);                 \
+        HIP_CHECK(hipGetLastError());                                                                           \
+    } while (0)
+                    stage_begin(1);
+                    PT_LAUNCH_AC(k_wf_trace, s.trace_blocks, s.dev, W, d_tiles, rngb, q_in, (uint4*)s.wf_hits.p, wctr, gctr);
+                    stage_end();
+                    ++launches;
+                    stage_begin(2);
+                    // PT_LAUNCH_AC launches 256-thread workgroups; the shade kernel wants WF_SHADE_THREADS
+                    PT_LAUNCH_SHADE(k_wf_shade, (uint32_t)(s.n_cu * 4), s.dev, W, d_tiles, rngb, (const float4*)q_in,
+                                 (const uint4*)s.wf_hits.p, q_out, (float4*)s.wf_shadow.p, (float4*)s.wf_contrib.p,
+                                 (float*)s.staging_buf.p, wctr, gctr);
+                    stage_end();
+                    stage_begin(3);
+                    PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, s.dev, W, (const float4*)s.wf_shadow.p,
+                                 (const float4*)s.wf_contrib.p, q_out, (float*)s.staging_buf.p, wctr, gctr);
+                    stage_end();
+#undef PT_LAUNCH_AC
+#undef PT_LAUNCH_SHADE
+                }
+            }
+        }
+        if (mode >= 1) {
+            stage_begin(4);
             hipLaunchKernelGGL(k_accumulate, dim3(((uint32_t)tm.n_local + 255u) / 256u), dim3(256), 0, stream,
                                (const float*)s.staging_buf.p, accum, (uint32_t)tm.n_local, nb, s0 == 0 ? 1 : 0);
             HIP_CHECK(hipGetLastError());
+            stage_end();
         }
-        ++launches;
         if (o.progress) {
             HIP_CHECK(hipStreamSynchronize(stream));
             o.progress(P.sample_end, p.samples, o.progress_user);
         }
     }
+    const size_t ev_post = ev;
     if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
     if (d_rgb8) {
         hipLaunchKernelGGL(k_postprocess, dim3(((uint32_t)tm.n_local + 255u) / 256u), dim3(256), 0, stream, accum,
@@ -809,20 +891,25 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     if (timing) {
         pt_timing t{};
         t.launches = launches;
-        for (uint32_t l = 0; l < launches; ++l) {
+        t.stage_launches = stage_launches;
+        float* slot[6] = {&t.generate_ms, &t.trace_ms, &t.shade_ms, &t.shadow_ms, &t.accumulate_ms, &t.integrate_ms};
+        static const bool dump = getenv("PT_DEBUG_TIMES") != nullptr;
+        for (auto& m : marks) {
             float ms = 0;
-            HIP_CHECK(hipEventElapsedTime(&ms, s.events[2 * l], s.events[2 * l + 1]));
-            t.integrate_ms += ms;
+            HIP_CHECK(hipEventElapsedTime(&ms, s.events[m.second], s.events[m.second + 1]));
+            *slot[m.first] += ms;
+            if (dump) fprintf(stderr, "[pt] stage %d  %.3f ms\n", m.first, ms);
         }
-        HIP_CHECK(hipEventElapsedTime(&t.postprocess_ms, s.events[2 * launches], s.events[2 * launches + 1]));
-        HIP_CHECK(hipEventElapsedTime(&t.total_ms, s.events[0], s.events[2 * launches + 1]));
+        if (mode == 2) t.integrate_ms = t.trace_ms;  // dominant kernel of the wavefront integrator
+        HIP_CHECK(hipEventElapsedTime(&t.postprocess_ms, s.events[ev_post], s.events[ev_post + 1]));
+        HIP_CHECK(hipEventElapsedTime(&t.total_ms, s.events[0], s.events[ev_post + 1]));
         s.timing = t;
     }
     if (counting) {
         DevCounters c;
         HIP_CHECK(hipMemcpy(&c, s.counter_buf.p, sizeof c, hipMemcpyDeviceToHost));
         s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
-                                 c.rng_draws, c.restarts};
+                                 c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes};
     }
 }
 

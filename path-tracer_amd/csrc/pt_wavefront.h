@@ -1,0 +1,871 @@
+// Wavefront integrator: the bounce loop of the reference (renderer/mod.rs:172-278) cut into
+// stage kernels that exchange compacted queues in HBM, so that every lane of a wavefront runs
+// the SAME stage (all traversing, or all shading) instead of serialising them against each
+// other inside one fused kernel (measured: 8 of 64 lanes active per VALU instruction there).
+//
+//   per chunk of work items (one item = one path sample, pt_gpu.hip decode_item):
+//     k_wf_generate                 ChaCha12 block + camera ray            -> queue[0]
+//     for bounce = 0 .. bounces:
+//        k_wf_trace   (persistent)  ray_cast + alpha walk                   -> hit[i]
+//        k_wf_shade                 material, BRDF, next ray, termination   -> queue[b+1], shadow queue
+//        k_wf_shadow  (persistent)  get_light_info per light, adds direct light, retires paths
+//   k_accumulate (pt_gpu.hip)       adds the staged samples per pixel in sample order
+//
+// Queue records are 16-byte vectors read and written by consecutive lanes (coalesced):
+//   PathRec  64 B  q0 = (o.xyz, d.x)  q1 = (d.yz, thr.xy)  q2 = (thr.z, color.xyz)
+//                  q3 = (item_rel, draw_idx | bounce << 16, out_slot, item_abs)
+//   HitRec   16 B  (pid | flags << 28 ... see pack_hit, key, u, v)
+//   ShadowRec 64 B s0 = (pos.xyz, gn.x) s1 = (gn.yz, uv.xy) s2 = (color.xyz, bits(next_index))
+//                  s3 = (bits(out_slot), bits(flags), 0, 0)     + contrib[light][k] float4
+// Survivors are compacted with one atomic per wavefront (ballot -> popcount -> mbcnt prefix).
+// The trace/shadow kernels are persistent: a lane whose ray is finished fetches the next queue
+// entry (same ballot/popcount scheme), so long traversals do not hold 63 idle lanes.
+#pragma once
+#include "pt_integrator.h"
+
+// Work item -> pixel / sample (see the item numbering in pt_gpu.hip).
+struct ItemRef {
+    uint32_t x, y, global_index, out_index, sample;  // sample is 1-based (mod.rs:105)
+    bool valid;
+};
+
+__device__ __forceinline__ ItemRef decode_item(const RenderParams& P, const uint32_t* __restrict__ tile_offsets,
+                                               uint32_t item) {
+    ItemRef r;
+    uint32_t batch = P.sample_end - P.sample_begin;
+    uint32_t lane = item & 63u;
+    uint32_t g = item >> 6;
+    uint32_t s_rel = g % batch, b64 = g / batch;
+    uint32_t blocks_per_tile = (P.tile_w >> 3) * (P.tile_h >> 3);
+    uint32_t lt = b64 / blocks_per_tile, sub = b64 % blocks_per_tile;
+    uint32_t waves_x = P.tile_w >> 3;
+    uint32_t tx = (sub % waves_x) * 8u + (lane & 7u);
+    uint32_t ty = (sub / waves_x) * 8u + (lane >> 3);
+    uint32_t k = P.shard_rank + lt * P.shard_count;
+    uint32_t tile_x = k % P.tiles_x, tile_y = k / P.tiles_x;
+    r.x = tile_x * P.tile_w + tx;
+    r.y = tile_y * P.tile_h + ty;
+    r.valid = tile_y < P.tiles_y && r.x < P.width && r.y < P.height;
+    r.global_index = r.x + r.y * P.width;
+    r.sample = P.sample_begin + 1u + s_rel;
+    if (P.shard_count <= 1) {
+        r.out_index = r.global_index;
+    } else {
+        uint32_t cw = min(P.tile_w, P.width - tile_x * P.tile_w);
+        r.out_index = tile_offsets[lt] + ty * cw + tx;
+    }
+    return r;
+}
+
+struct WfParams {
+    RenderParams P;
+    uint32_t item_base;   // first absolute work item of this chunk
+    uint32_t n_items;     // items in this chunk
+    uint32_t cap;         // queue capacity (records)
+    uint32_t bounce;      // current bounce (shade / shadow)
+    uint32_t refill_min;  // idle lanes that trigger a queue refill in the persistent kernels
+    uint32_t walk_steps;  // node steps per walking phase
+};
+
+struct WfCounters {  // one set per bounce level, zeroed once per chunk
+    uint32_t queue_count;    // records in queue[b]
+    uint32_t shadow_count;   // records in the shadow queue of bounce b
+    uint32_t trace_work;     // dynamic fetch cursors
+    uint32_t shadow_work;
+};
+
+#define WF_FLAG_TERMINATED 1u
+#define WF_FLAG_SPHERE 2u
+
+PT_D uint32_t wf_lane_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Reserve `popcount(ballot(want))` consecutive slots with one atomic per wavefront.
+PT_D uint32_t wf_reserve(uint32_t* counter, bool want) {
+    unsigned long long m = __ballot(want);
+    if (!m) return 0;
+    int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)__lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + wf_lane_rank(m);
+}
+
+// Queue consumption for the persistent kernels.  One returning atomic on a single word
+// saturates at ~88 per microsecond on MI355X (MI355X_MICROARCH.md, "dequeue"), which a
+// per-refill atomic hits at a few hundred Mrays/s; so a wavefront reserves WF_CHUNK entries at a
+// time and hands them to its idle lanes from wave-uniform registers (ballot + mbcnt prefix).
+#define WF_CHUNK 512u
+struct WaveFetch {
+    uint32_t cur, end;
+    bool done;
+};
+
+PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursor, uint32_t n, bool need, bool& got, bool& exhausted) {
+    got = false;
+    unsigned long long m = __ballot(need);
+    if (!m) return 0;
+    if (wf.cur >= wf.end && !wf.done) {
+        int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)__lane_id() == leader) base = atomicAdd(cursor, WF_CHUNK);
+        base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
+        if (base >= n) {
+            wf.done = true;
+        } else {
+            wf.cur = base;
+            wf.end = base + WF_CHUNK < n ? base + WF_CHUNK : n;
+        }
+    }
+    uint32_t w = 0;
+    if (wf.cur < wf.end) {
+        uint32_t rank = wf_lane_rank(m), avail = wf.end - wf.cur, want = (uint32_t)__popcll(m);
+        if (need && rank < avail) {
+            got = true;
+            w = wf.cur + rank;
+        }
+        wf.cur += want < avail ? want : avail;
+    } else if (wf.done && need) {
+        exhausted = true;
+    }
+    return w;
+}
+
+// ---------------------------------------------------------------------------
+// Resumable KD traversal (same decisions as kd_traverse in pt_integrator.h), one node per
+// call so that the kernels can run it in phases.
+//
+// Stack: the first WF_LDS_STACK entries of every lane live in LDS ([entry][thread], 8 B each,
+// conflict-free because the entry stride is a multiple of the bank row), deeper entries
+// overflow into a per-lane scratch array.  Almost all pushes stay within the LDS part, which
+// takes the stack traffic off the vector-memory path (it was 2 GB of HBM writes per 33 M rays).
+// ---------------------------------------------------------------------------
+#define WF_LDS_STACK 8
+#define WF_THREADS 256
+
+struct Trav {
+    f3 o, d, inv;
+    float tmin, tmax, key_scale;
+    uint32_t node;
+    int sp;
+    uint2 leaf;   // the non-empty leaf the lane is holding (valid when trav_step returned 1)
+};
+
+struct TravStack {
+    uint2* lds;            // this thread's column: entry e at lds[e * WF_THREADS]
+    uint32_t* ov_node;     // overflow (scratch)
+    float* ov_tmax;
+};
+
+PT_D void stack_push(const TravStack& st, int sp, uint32_t node, float tmax) {
+    if (sp < WF_LDS_STACK) {
+        st.lds[sp * WF_THREADS] = make_uint2(node, __float_as_uint(tmax));
+    } else {
+        st.ov_node[sp - WF_LDS_STACK] = node;
+        st.ov_tmax[sp - WF_LDS_STACK] = tmax;
+    }
+}
+PT_D void stack_get(const TravStack& st, int sp, uint32_t& node, float& tmax) {
+    if (sp < WF_LDS_STACK) {
+        uint2 e = st.lds[sp * WF_THREADS];
+        node = e.x;
+        tmax = __uint_as_float(e.y);
+    } else {
+        node = st.ov_node[sp - WF_LDS_STACK];
+        tmax = st.ov_tmax[sp - WF_LDS_STACK];
+    }
+}
+
+PT_D bool trav_start(const DevScene& S, Trav& T, f3 o, f3 d, float t_start) {
+    T.o = o;
+    T.d = d;
+    T.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float dlen = mag3(d);
+    T.key_scale = dlen < 1.0f ? dlen : 1.0f;
+    float tmin = t_start, tmax = INFINITY;
+    const float oa[3] = {o.x, o.y, o.z}, ia[3] = {T.inv.x, T.inv.y, T.inv.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float tn = (S.bounds_min[a] - oa[a]) * ia[a];
+        float tf = (S.bounds_max[a] - oa[a]) * ia[a];
+        if (tn > tf) {
+            float tmp = tn;
+            tn = tf;
+            tf = tmp;
+        }
+        tmin = tn > tmin ? tn : tmin;
+        tmax = tf < tmax ? tf : tmax;
+    }
+    T.tmin = tmin;
+    T.tmax = tmax;
+    T.node = 0;
+    T.sp = 0;
+    return !(tmin > tmax);
+}
+
+// Move to the next stacked segment; false when the walk is over (stack empty or the segment
+// starts beyond `limit`, the best hit key so far).
+PT_D bool trav_pop(Trav& T, const TravStack& st, float limit) {
+    if (T.sp == 0) return false;
+    --T.sp;
+    T.tmin = T.tmax;
+    stack_get(st, T.sp, T.node, T.tmax);
+    return !(T.tmin * T.key_scale > limit * PT_EXIT_REL + PT_EXIT_ABS);
+}
+
+// One node.  Returns 0 = still walking, 1 = holding a non-empty leaf (T.leaf), 2 = walk over.
+template <bool COUNT>
+PT_D int trav_step(const DevScene& S, Trav& T, const TravStack& st, float limit, LocalCtr& lc) {
+    uint2 nd = S.kd_nodes[T.node];
+    if (COUNT) lc.nodes++;
+    uint32_t axis = nd.y & 3u;
+    if (axis != 3u) {
+        float split = __uint_as_float(nd.x);
+        float oax = axis == 0 ? T.o.x : (axis == 1 ? T.o.y : T.o.z);
+        float dax = axis == 0 ? T.d.x : (axis == 1 ? T.d.y : T.d.z);
+        float iax = axis == 0 ? T.inv.x : (axis == 1 ? T.inv.y : T.inv.z);
+        float tplane = (split - oax) * iax;
+        bool below_first = (oax < split) || (oax == split && dax <= 0.f);
+        uint32_t below = T.node + 1, above = nd.y >> 2;
+        uint32_t first = below_first ? below : above;
+        uint32_t second = below_first ? above : below;
+        if (tplane > T.tmax * PT_EXIT_REL + PT_EXIT_ABS || tplane <= 0.f) {
+            T.node = first;
+        } else if (tplane < T.tmin * (2.f - PT_EXIT_REL) - PT_EXIT_ABS) {
+            T.node = second;
+        } else {
+            stack_push(st, T.sp, second, T.tmax);
+            ++T.sp;
+            T.node = first;
+            T.tmax = tplane;
+        }
+        return 0;
+    }
+    if (nd.y >> 2) {
+        T.leaf = nd;
+        return 1;
+    }
+    return trav_pop(T, st, limit) ? 0 : 2;  // empty leaf: straight on to the next segment
+}
+
+// Closest-hit candidate update for one leaf (same acceptance rule as next_hit()).
+template <bool COUNT>
+PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_prev, uint32_t ord_prev, RawHit& best,
+                       LocalCtr& lc) {
+    const float4* lp = S.leaf_prims + (size_t)leaf.x * 3;
+    uint32_t n = leaf.y >> 2;
+    for (uint32_t i = 0; i < n; ++i) {
+        float4 q0 = lp[3 * i], q1 = lp[3 * i + 1], q2 = lp[3 * i + 2];
+        uint32_t pid = __float_as_uint(q0.w);
+        if (COUNT) lc.tris++;
+        if (!(pid & PT_PRIM_SPHERE)) {
+            float dist, u, v;
+            bool bf;
+            if (!isect_triangle(T.o, T.d, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), dist, u,
+                                v, bf))
+                continue;
+            uint32_t ord = pid * 2u;
+            if (key_less(t_prev, ord_prev, dist, ord) && key_less(dist, ord, best.key, best.ord)) {
+                best.key = dist;
+                best.ord = ord;
+                best.pid = pid;
+                best.u = u;
+                best.v = v;
+                best.flags = bf ? 1u : 0u;
+            }
+        } else {
+            float t[2], key[2];
+            bool ex[2];
+            int nh = isect_sphere(T.o, T.d, mk3(q0.x, q0.y, q0.z), q1.x, t, key, ex);
+            for (int k = 0; k < nh; ++k) {
+                uint32_t ord = (pid & ~PT_PRIM_SPHERE) * 2u + (ex[k] ? 1u : 0u);
+                if (key[k] == key[k] && key_less(t_prev, ord_prev, key[k], ord) && key_less(key[k], ord, best.key, best.ord)) {
+                    best.key = key[k];
+                    best.ord = ord;
+                    best.pid = pid;
+                    best.u = t[k];
+                    best.v = 0.f;
+                    best.flags = 2u | (ex[k] ? 4u : 0u);
+                }
+            }
+        }
+    }
+}
+
+PT_D float next_start(float t_prev, f3 d) {  // where a continuation cast may start (see next_hit)
+    float dlen = mag3(d);
+    float t_start = t_prev > 0.f ? t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f) * 0.99999f - 1e-6f : 0.f;
+    return t_start > 0.f ? t_start : 0.f;
+}
+
+// HitRec packing: x = pid (bit 31 sphere), y = bits(key), z = bits(u), w = bits(v) with the
+// flags in a separate word is wasteful; backface / exit flags ride in the low bits of a 5th
+// value folded into `ord`: ord = prim*2 + exit is recomputable, backface is bit 30 of x.
+PT_D uint4 pack_hit(const RawHit& h, bool hit) {
+    if (!hit) return make_uint4(0xffffffffu, 0u, 0u, 0u);
+    uint32_t x = (h.pid & 0x8fffffffu) | ((h.flags & 1u) << 30) | ((h.flags & 4u) << 27);  // bit31 sphere, bit30 backface, bit29 exit
+    return make_uint4(x, __float_as_uint(h.key), __float_as_uint(h.u), __float_as_uint(h.v));
+}
+PT_D bool unpack_hit(uint4 r, RawHit& h) {
+    if (r.x == 0xffffffffu) return false;
+    bool sphere = (r.x & PT_PRIM_SPHERE) != 0;
+    uint32_t prim = r.x & 0x0fffffffu;
+    h.pid = prim | (sphere ? PT_PRIM_SPHERE : 0u);
+    h.flags = ((r.x >> 30) & 1u) | (sphere ? 2u : 0u) | (((r.x >> 29) & 1u) << 2);
+    h.key = __uint_as_float(r.y);
+    h.u = __uint_as_float(r.z);
+    h.v = __uint_as_float(r.w);
+    h.ord = prim * 2u + ((h.flags >> 2) & 1u);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// generate: RNG block + camera ray for every valid item of the chunk
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wf_generate(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
+                                                     uint32_t* __restrict__ rng_blocks, float4* __restrict__ queue,
+                                                     WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
+    // No compaction here: queue[0] slot = item (the only invalid items are the 8x8 blocks that
+    // hang over the image border); an invalid item is a record with out_slot = ~0 that the
+    // trace kernel answers with "no hit" and the shade kernel drops.
+    uint32_t rel = blockIdx.x * 256u + threadIdx.x;
+    if (rel == 0) ctr[0].queue_count = W.n_items;
+    if (rel >= W.n_items) return;
+    ItemRef it = decode_item(W.P, tile_offsets, W.item_base + rel);
+    float4* q = queue + (size_t)rel * 4;
+    if (!it.valid) {
+        q[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q[3] = make_float4(__uint_as_float(rel), __uint_as_float(2u), __uint_as_float(0xffffffffu),
+                           __uint_as_float(W.item_base + rel));
+        return;
+    }
+    if (gctr) {
+        atomicAdd(&gctr->samples, 1ull);
+        atomicAdd(&gctr->rng_draws, 2ull);
+    }
+    uint32_t w[16];
+    uint64_t seed = (uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples;
+    pt_chacha12_block(seed, 0u, w);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rng_blocks[(size_t)i * W.cap + rel] = w[i];
+    float r1 = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
+    float r2 = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+    f3 o, d;
+    primary_ray(S, it.x, it.y, W.P.width, W.P.height, r1, r2, o, d);
+    uint32_t out_slot = (it.sample - 1u - W.P.sample_begin) * W.P.n_local + it.out_index;
+    q[0] = make_float4(o.x, o.y, o.z, d.x);
+    q[1] = make_float4(d.y, d.z, 1.f, 1.f);
+    q[2] = make_float4(1.f, 0.f, 0.f, 0.f);
+    q[3] = make_float4(__uint_as_float(rel), __uint_as_float(2u), __uint_as_float(out_slot),
+                       __uint_as_float(W.item_base + rel));
+}
+
+// rng.gen::<f32>() number idx of the item (first block staged by k_wf_generate).
+PT_D float wf_draw(const DevScene& S, const WfParams& W, const uint32_t* __restrict__ tile_offsets,
+                   const uint32_t* __restrict__ rng_blocks, uint32_t item_rel, uint32_t item_abs, uint32_t idx) {
+    uint32_t word;
+    if (idx < 16u) {
+        word = rng_blocks[(size_t)idx * W.cap + item_rel];
+    } else {
+        ItemRef it = decode_item(W.P, tile_offsets, item_abs);
+        uint64_t seed = (uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples;
+        uint32_t w[16];
+        pt_chacha12_block(seed, idx >> 4, w);
+        word = w[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) word = (idx & 15u) == (uint32_t)i ? w[i] : word;
+    }
+    return (float)(word >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---------------------------------------------------------------------------
+// trace: persistent closest-hit traversal with the alpha walk (mod.rs:182-205)
+//
+// Loop of every wavefront:
+//   refill   idle lanes take queue entries (once enough lanes are idle)
+//   phase A  up to walk_steps node steps: interior nodes and EMPTY leaves (85 % of the leaf
+//            visits) are handled here by all walking lanes together; a lane that reaches a
+//            non-empty leaf parks
+//   phase B  the parked lanes run Möller–Trumbore over their leaves together, then pop
+// ---------------------------------------------------------------------------
+template <bool ALPHA, bool COUNT>
+__global__ __launch_bounds__(WF_THREADS) void k_wf_trace(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
+                                                         const uint32_t* __restrict__ rng_blocks,
+                                                         float4* __restrict__ queue, uint4* __restrict__ hits,
+                                                         WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
+    __shared__ uint2 lds_stack[WF_LDS_STACK * WF_THREADS];
+    const uint32_t n = ctr[W.bounce].queue_count;
+    uint32_t* cursor = &ctr[W.bounce].trace_work;
+    uint32_t ov_node[PT_KD_STACK - WF_LDS_STACK];
+    float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
+    const TravStack st = {lds_stack + threadIdx.x, ov_node, ov_tmax};
+    Trav T;
+    RawHit best, kept;       // kept: the last surface of the alpha walk when every hit was skipped
+    bool have_kept = false;
+    float t_prev = -INFINITY;
+    uint32_t ord_prev = 0, idx = 0, item_rel = 0, item_abs = 0, draw = 0;
+    bool active = false, exhausted = false, at_leaf = false, cast_done = false;
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};
+    uint32_t cast_nodes0 = 0;
+    WaveFetch wf = {0u, 0u, false};
+
+    // the current cast has no further segment: best = next entry of the sorted hit list (or none)
+    // (called from ONE place per loop iteration to keep the kernel's register footprint small)
+    auto complete = [&]() {
+        cast_done = false;
+        bool hit = best.pid != 0xffffffffu;
+        bool finished = true;
+        if (ALPHA && hit) {
+            Surface sf;
+            make_surface(S, T.o, T.d, best, sf);
+            float opacity = material_opacity(S, sf.model, sf.sphere, sf.uv);
+            if (COUNT) lc.shaded++;
+            bool stop = opacity >= 1.f;
+            if (!stop && opacity > 0.001f) {
+                float r = wf_draw(S, W, tile_offsets, rng_blocks, item_rel, item_abs, draw++);
+                stop = r < opacity;
+                if (COUNT) lc.shadow_rays++;  // (re-used as the alpha-draw counter in this kernel)
+            }
+            if (!stop) {  // skipped: remember it and look for the next entry
+                kept = best;
+                have_kept = true;
+                t_prev = best.key;
+                ord_prev = best.ord;
+                best.key = INFINITY;
+                best.ord = 0xffffffffu;
+                best.pid = 0xffffffffu;
+                finished = !trav_start(S, T, T.o, T.d, next_start(t_prev, T.d));
+                if (COUNT) lc.restarts++;
+                if (finished) hit = false;
+            }
+        }
+        if (finished) {
+            if (COUNT) {
+                uint32_t nn = lc.nodes - cast_nodes0;
+                atomicMax(&gctr->max_nodes_per_cast, (unsigned long long)nn);
+                if (nn > 1000u) atomicAdd(&gctr->casts_over_1k_nodes, 1ull);
+            }
+            if (ALPHA && !hit && have_kept) {  // every hit skipped: the last one is shaded
+                best = kept;
+                hit = true;
+            }
+            hits[idx] = pack_hit(best, hit);
+            if (ALPHA) {
+                float4* q = queue + (size_t)idx * 4;
+                float4 q3 = q[3];
+                uint32_t packed = (__float_as_uint(q3.y) & 0xffff0000u) | (draw & 0xffffu);
+                q[3] = make_float4(q3.x, __uint_as_float(packed), q3.z, q3.w);
+            }
+            active = false;
+        }
+    };
+
+    while (true) {
+        // ---- refill
+        bool need = !active && !exhausted;
+        unsigned long long m_need = __ballot(need);
+        if (m_need && ((uint32_t)__popcll(m_need) >= W.refill_min || !__any(active))) {
+            bool got;
+            uint32_t w = wave_fetch(wf, cursor, n, need, got, exhausted);
+            if (got) {
+                idx = w;
+                const float4* q = queue + (size_t)idx * 4;
+                float4 q0 = q[0], q1 = q[1], q3 = q[3];
+                f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
+                const bool valid_item = __float_as_uint(q3.z) != 0xffffffffu;
+                if (ALPHA) {
+                    item_rel = __float_as_uint(q3.x);
+                    draw = __float_as_uint(q3.y) & 0xffffu;
+                    item_abs = __float_as_uint(q3.w);
+                }
+                if (COUNT && valid_item) lc.segments++;
+                if (COUNT) cast_nodes0 = lc.nodes;
+                t_prev = -INFINITY;
+                ord_prev = 0;
+                have_kept = false;
+                best.key = INFINITY;
+                best.ord = 0xffffffffu;
+                best.pid = 0xffffffffu;
+                active = true;
+                at_leaf = false;
+                // outside the image / misses the scene box: answered as "no hit" below
+                cast_done = !valid_item || !trav_start(S, T, o, d, 0.f);
+            }
+        }
+        if (!__any(active)) {
+            if (__all(exhausted)) break;
+            continue;
+        }
+        // ---- phase A: walk
+        for (uint32_t k = 0; k < W.walk_steps; ++k) {
+            bool walking = active && !at_leaf && !cast_done;
+            if (!__any(walking)) break;
+            if (walking) {
+                int r = trav_step<COUNT>(S, T, st, best.key, lc);
+                at_leaf = r == 1;
+                cast_done = r == 2;
+            }
+        }
+        // ---- phase B: primitives of the parked leaves
+        if (active && at_leaf) {
+            leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc);
+            at_leaf = false;
+            cast_done = !trav_pop(T, st, best.key);
+        }
+        if (active && cast_done) complete();
+    }
+    if (COUNT) {
+        atomicAdd(&gctr->segments, (unsigned long long)lc.segments);
+        atomicAdd(&gctr->nodes_visited, (unsigned long long)lc.nodes);
+        atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
+        if (ALPHA) atomicAdd(&gctr->shaded_hits, (unsigned long long)lc.shaded);
+        if (ALPHA) atomicAdd(&gctr->rng_draws, (unsigned long long)lc.shadow_rays);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// shade: compute_radiance without the light visibility (mod.rs:230-278)
+// ---------------------------------------------------------------------------
+#define WF_SHADE_THREADS 512
+template <bool ALPHA, bool COUNT>
+__global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
+                                                  const uint32_t* __restrict__ rng_blocks,
+                                                  const float4* __restrict__ queue_in, const uint4* __restrict__ hits,
+                                                  float4* __restrict__ queue_out, float4* __restrict__ shadow_q,
+                                                  float4* __restrict__ contrib, float* __restrict__ staging,
+                                                  WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
+    const uint32_t n = ctr[W.bounce].queue_count;
+    uint32_t n_draws = 0;
+    __shared__ uint32_t sh_cnt[2][WF_SHADE_THREADS / 64];
+    __shared__ uint32_t sh_base[2];
+    const uint32_t wave = threadIdx.x >> 6;
+    // grid-stride over the queue, one workgroup-wide step at a time (the loop bound is uniform in
+    // the workgroup: every thread reaches the barriers of the compaction)
+    for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS) {
+    uint32_t i = base + threadIdx.x;
+    bool live = i < n;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), color = mk3(0, 0, 0);
+    uint32_t item_rel = 0, item_abs = 0, draw = 0, out_slot = 0;
+    RawHit h;
+    bool hit = false;
+    if (live) {
+        const float4* q = queue_in + (size_t)i * 4;
+        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        o = mk3(q0.x, q0.y, q0.z);
+        d = mk3(q0.w, q1.x, q1.y);
+        thr = mk3(q1.z, q1.w, q2.x);
+        color = mk3(q2.y, q2.z, q2.w);
+        item_rel = __float_as_uint(q3.x);
+        draw = __float_as_uint(q3.y) & 0xffffu;
+        out_slot = __float_as_uint(q3.z);
+        item_abs = __float_as_uint(q3.w);
+        hit = unpack_hit(hits[i], h);
+        if (out_slot == 0xffffffffu) live = false;  // item outside the image (k_wf_generate)
+    }
+    const uint32_t bounce = W.bounce, bounces = W.P.bounces;
+    bool to_shadow = false, survive = false;
+    Surface surf;
+    f3 next_o = o, next_d = d, next_thr = thr;
+    if (live && !hit) {  // background (mod.rs:184-186): the path ends here
+        color = color + mul_ew(thr, ld3(S.background));
+        float* out = staging + (size_t)out_slot * 3;
+        out[0] = color.x;
+        out[1] = color.y;
+        out[2] = color.z;
+    }
+    Brdf brdf;
+    f3 normal = mk3(0, 0, 0), view = mk3(0, 0, 0);
+    if (live && hit) {
+        make_surface(S, o, d, h, surf);
+        MatSample ms;
+        material_sample(S, surf.model, surf.sphere, surf.uv, ms);
+        normal = shading_normal(S, surf);
+        if (COUNT && !ALPHA) atomicAdd(&gctr->shaded_hits, 1ull);
+        view = -1.f * d;
+        ct_init(brdf, ms);
+        color = color + mul_ew(thr, ms.emissive);
+        to_shadow = true;
+        bool ended = false;
+        if (bounce < bounces) {
+            next_o = surf.pos + surf.normal * 0.00001f;
+            float r1 = wf_draw(S, W, tile_offsets, rng_blocks, item_rel, item_abs, draw++);
+            float r2 = wf_draw(S, W, tile_offsets, rng_blocks, item_rel, item_abs, draw++);
+            next_d = ct_sample(brdf, normal, view, r1, r2);
+            f3 wgt = ct_eval_indirect(brdf, normal, view, next_d) / 1.0f;
+            next_thr = mul_ew(thr, wgt);
+        }
+        if (dot3(next_thr, next_thr) < 0.00001f) ended = true;
+        if (!ended && bounce > 3) {
+            float p = max_rs(max_rs(next_thr.x, next_thr.y), next_thr.z);
+            next_thr = next_thr * (1.f / p);
+            if (wf_draw(S, W, tile_offsets, rng_blocks, item_rel, item_abs, draw++) > p) ended = true;
+        }
+        survive = !ended && bounce + 1 <= bounces;
+    }
+    // ---- compaction: survivors -> queue[b+1], surface hits -> shadow queue.  One atomic per
+    // workgroup and queue (wave ballots -> LDS -> one lane), not one per wavefront: the counter
+    // word would otherwise cap the kernel at ~88 M wave-atomics per second.
+    unsigned long long m_next = __ballot(survive), m_sh = __ballot(to_shadow);
+    if ((threadIdx.x & 63u) == 0) {
+        sh_cnt[0][wave] = (uint32_t)__popcll(m_next);
+        sh_cnt[1][wave] = (uint32_t)__popcll(m_sh);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < WF_SHADE_THREADS / 64; ++k) total += sh_cnt[threadIdx.x][k];
+        uint32_t* counter = threadIdx.x == 0 ? &ctr[bounce + 1].queue_count : &ctr[bounce].shadow_count;
+        sh_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t next_idx = sh_base[0] + wf_lane_rank(m_next), sh_idx = sh_base[1] + wf_lane_rank(m_sh);
+    for (uint32_t k = 0; k < wave; ++k) {
+        next_idx += sh_cnt[0][k];
+        sh_idx += sh_cnt[1][k];
+    }
+    __syncthreads();  // sh_cnt / sh_base are rewritten by the next step
+    if (survive) {
+        float4* q = queue_out + (size_t)next_idx * 4;
+        q[0] = make_float4(next_o.x, next_o.y, next_o.z, next_d.x);
+        q[1] = make_float4(next_d.y, next_d.z, next_thr.x, next_thr.y);
+        q[2] = make_float4(next_thr.z, color.x, color.y, color.z);  // colour is patched by k_wf_shadow
+        q[3] = make_float4(__uint_as_float(item_rel), __uint_as_float((draw & 0xffffu) | ((bounce + 1) << 16)),
+                           __uint_as_float(out_slot), __uint_as_float(item_abs));
+    }
+    if (to_shadow) {
+        float4* sq = shadow_q + (size_t)sh_idx * 4;
+        sq[0] = make_float4(surf.pos.x, surf.pos.y, surf.pos.z, surf.normal.x);
+        sq[1] = make_float4(surf.normal.y, surf.normal.z, surf.uv.x, surf.uv.y);
+        sq[2] = make_float4(color.x, color.y, color.z, __uint_as_float(survive ? next_idx : 0xffffffffu));
+        sq[3] = make_float4(__uint_as_float(out_slot), __uint_as_float(surf.sphere ? WF_FLAG_SPHERE : 0u), 0.f, 0.f);
+        // (thr ⊙ eval_direct) per light; the visibility factor is applied by k_wf_shadow
+        for (uint32_t li = 0; li < S.n_lights; ++li) {
+            const DevLight& L = S.lights[li];
+            f3 ldir = L.kind == PT_LIGHT_POINT ? normalize3(surf.pos - ld3(L.vec)) : ld3(L.vec);
+            f3 c = mul_ew(thr, ct_eval_direct(brdf, normal, view, -1.f * ldir));
+            contrib[(size_t)li * W.cap + sh_idx] = make_float4(c.x, c.y, c.z, 0.f);
+        }
+    }
+    if (COUNT && live) n_draws += draw - (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu);
+    }  // grid-stride loop
+    if (COUNT && n_draws) atomicAdd(&gctr->rng_draws, (unsigned long long)n_draws);
+}
+
+// ---------------------------------------------------------------------------
+// shadow: get_light_info for every light of every shaded surface (mod.rs:281-333), adds the
+// direct light in light order and retires finished paths.  Same refill / walk / leaf phases as
+// k_wf_trace; a job is one shaded surface, its lights are cast one after the other.
+// ---------------------------------------------------------------------------
+template <bool ALPHA, bool COUNT>
+__global__ __launch_bounds__(WF_THREADS) void k_wf_shadow(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
+                                                          const float4* __restrict__ contrib,
+                                                          float4* __restrict__ queue_next, float* __restrict__ staging,
+                                                          WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
+    __shared__ uint2 lds_stack[WF_LDS_STACK * WF_THREADS];
+    const uint32_t n = ctr[W.bounce].shadow_count;
+    uint32_t* cursor = &ctr[W.bounce].shadow_work;
+    uint32_t ov_node[PT_KD_STACK - WF_LDS_STACK];
+    float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
+    const TravStack st = {lds_stack + threadIdx.x, ov_node, ov_tmax};
+    Trav T;
+    // per-lane job state
+    uint32_t idx = 0, li = 0, out_slot = 0, next_idx = 0;
+    f3 pos = mk3(0, 0, 0), gn = mk3(0, 0, 0), color = mk3(0, 0, 0), rad = mk3(0, 0, 0);
+    f2 uv = {0.f, 0.f};
+    bool sphere = false, point = false, blocked = false;
+    float ldist = 0.f, limit = INFINITY, t_prev = -INFINITY;
+    uint32_t ord_prev = 0;
+    RawHit best;
+    best.key = INFINITY;
+    best.ord = 0xffffffffu;
+    best.pid = 0xffffffffu;
+    bool active = false, exhausted = false, at_leaf = false, cast_done = false, need_begin = false;
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};
+    WaveFetch wf = {0u, 0u, false};
+
+    auto add_light = [&]() {  // visibility known: add the light (mod.rs:251-261)
+        if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) {
+            float4 c = contrib[(size_t)li * W.cap + idx];
+            color = color + mul_ew(mk3(c.x, c.y, c.z), rad);
+        }
+        ++li;
+    };
+    // start the cast for light li of the current job; false when the job has no more lights
+    auto begin_light = [&]() -> bool {
+        while (li < S.n_lights) {
+            const DevLight& L = S.lights[li];
+            point = L.kind == PT_LIGHT_POINT;
+            f3 direction;
+            rad = ld3(L.color);
+            if (point) {
+                direction = pos - ld3(L.vec);
+                ldist = mag3(direction);
+                direction = normalize3(direction);
+                rad = rad / (4.f * PT_PI * ldist * ldist);
+            } else {
+                direction = ld3(L.vec);
+                ldist = 0.f;
+            }
+            f3 so = pos + gn * 0.00001f;
+            f3 sd = -1.f * direction;
+            if (COUNT) lc.shadow_rays++;
+            blocked = false;
+            t_prev = -INFINITY;
+            ord_prev = 0;
+            best.key = INFINITY;
+            best.ord = 0xffffffffu;
+            best.pid = 0xffffffffu;
+            // opaque scenes: hits farther than the light cannot pass the range test
+            limit = (!ALPHA && point) ? (ldist + 1e-4f) * 1.0001f : INFINITY;
+            at_leaf = false;
+            if (trav_start(S, T, so, sd, 0.f)) return true;
+            add_light();  // the shadow ray misses the scene box: unoccluded
+        }
+        return false;
+    };
+    auto retire = [&]() {
+        if (next_idx == 0xffffffffu) {
+            float* out = staging + (size_t)out_slot * 3;
+            out[0] = color.x;
+            out[1] = color.y;
+            out[2] = color.z;
+        } else {
+            float4* q = queue_next + (size_t)next_idx * 4 + 2;
+            float4 q2 = *q;
+            *q = make_float4(q2.x, color.x, color.y, color.z);
+        }
+        active = false;
+    };
+    // the current cast has no further segment (ONE call site per loop iteration)
+    auto complete = [&]() {
+        cast_done = false;
+        if (ALPHA) {
+            // best = next entry of the sorted list: attenuate, then look for the following one
+            bool more = best.pid != 0xffffffffu;
+            if (more) {
+                float opacity = 0.f;
+                if (point) {
+                    f3 sp = T.o + T.d * ((best.flags & 2u) ? best.u : best.key);
+                    if (mag3(sp - pos) > ldist) {
+                        more = false;
+                    } else {
+                        // the SHADED hit's kind / uv with the occluder's material (mod.rs:324)
+                        uint32_t smodel = __float_as_uint(S.prim_attr[(size_t)(best.pid & ~PT_PRIM_SPHERE) * 4 + 3].w);
+                        opacity = material_opacity(S, smodel, sphere, uv);
+                    }
+                } else {
+                    Surface sh;
+                    make_surface(S, T.o, T.d, best, sh);
+                    opacity = material_opacity(S, sh.model, sh.sphere, sh.uv);
+                }
+                if (more) {
+                    rad = rad * (1.f - opacity);
+                    if (sum3(rad) == 0.f) more = false;
+                }
+            }
+            if (more) {
+                t_prev = best.key;
+                ord_prev = best.ord;
+                best.key = INFINITY;
+                best.ord = 0xffffffffu;
+                best.pid = 0xffffffffu;
+                if (COUNT) lc.restarts++;
+                if (trav_start(S, T, T.o, T.d, next_start(t_prev, T.d))) return;  // keep walking
+            }
+        } else if (blocked) {
+            rad = rad * 0.0f;
+        }
+        add_light();
+        need_begin = true;   // next light (or retire) at the top of the next iteration
+    };
+
+    while (true) {
+        bool need = !active && !exhausted;
+        unsigned long long m_need = __ballot(need);
+        if (m_need && ((uint32_t)__popcll(m_need) >= W.refill_min || !__any(active))) {
+            bool got;
+            uint32_t w = wave_fetch(wf, cursor, n, need, got, exhausted);
+            if (got) {
+                idx = w;
+                const float4* sq = shadow_q + (size_t)idx * 4;
+                float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3];
+                pos = mk3(s0.x, s0.y, s0.z);
+                gn = mk3(s0.w, s1.x, s1.y);
+                uv = {s1.z, s1.w};
+                color = mk3(s2.x, s2.y, s2.z);
+                next_idx = __float_as_uint(s2.w);
+                out_slot = __float_as_uint(s3.x);
+                sphere = (__float_as_uint(s3.y) & WF_FLAG_SPHERE) != 0;
+                li = 0;
+                active = true;
+                need_begin = true;
+            }
+        }
+        if (active && need_begin) {  // the ONE place a light's shadow cast starts
+            need_begin = false;
+            cast_done = false;
+            if (!begin_light()) retire();
+        }
+        if (!__any(active)) {
+            if (__all(exhausted)) break;
+            continue;
+        }
+        // ---- phase A: walk
+        for (uint32_t k = 0; k < W.walk_steps; ++k) {
+            bool walking = active && !at_leaf && !cast_done;
+            if (!__any(walking)) break;
+            if (walking) {
+                int r = trav_step<COUNT>(S, T, st, ALPHA ? best.key : limit, lc);
+                at_leaf = r == 1;
+                cast_done = r == 2;
+            }
+        }
+        // ---- phase B
+        if (active && at_leaf) {
+            at_leaf = false;
+            if (!ALPHA) {
+                // every opacity is exactly 1: any hit inside the light's range blocks it
+                const float4* lp = S.leaf_prims + (size_t)T.leaf.x * 3;
+                uint32_t np = T.leaf.y >> 2;
+                for (uint32_t i = 0; i < np && !blocked; ++i) {
+                    float4 q0 = lp[3 * i], q1 = lp[3 * i + 1], q2 = lp[3 * i + 2];
+                    uint32_t pid = __float_as_uint(q0.w);
+                    if (COUNT) lc.tris++;
+                    if (!(pid & PT_PRIM_SPHERE)) {
+                        float t, u, v;
+                        bool bf;
+                        if (!isect_triangle(T.o, T.d, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z),
+                                            mk3(q1.w, q2.x, q2.y), t, u, v, bf))
+                            continue;
+                        if (point && mag3((T.o + T.d * t) - pos) > ldist) continue;
+                        blocked = true;
+                    } else {
+                        float t[2], key[2];
+                        bool ex[2];
+                        int nh = isect_sphere(T.o, T.d, mk3(q0.x, q0.y, q0.z), q1.x, t, key, ex);
+                        for (int k = 0; k < nh; ++k) {
+                            if (!(key[k] == key[k])) continue;
+                            if (point && mag3((T.o + T.d * t[k]) - pos) > ldist) continue;
+                            blocked = true;
+                        }
+                    }
+                }
+                cast_done = blocked || !trav_pop(T, st, limit);
+            } else {
+                leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc);
+                cast_done = !trav_pop(T, st, best.key);
+            }
+        }
+        if (active && cast_done) complete();
+    }
+    if (COUNT) {
+        atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);
+        atomicAdd(&gctr->nodes_visited, (unsigned long long)lc.nodes);
+        atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
+    }
+}
