@@ -192,7 +192,7 @@ def gpu_lib():
     """libptgpu.so: the HIP integrator behind the C ABI.  Fails loudly when missing."""
     global _gpu
     if _gpu is None:
-        path = PKG_DIR / "libptgpu.so"
+        path = Path(os.environ.get("PT_GPU_LIB", PKG_DIR / "libptgpu.so"))  # override: A/B builds only
         if not path.exists():
             raise PtError(-4, f"{path} is missing: the HIP extension was not built "
                               "(run `make gpu` or __graft_entry__.build()); there is no CPU fallback")

@@ -717,7 +717,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     }();
     static const uint32_t wf_walk = [] {
         const char* e = getenv("PT_WF_WALK");
-        return (uint32_t)(e && *e ? atoi(e) : 12);
+        return (uint32_t)(e && *e ? atoi(e) : 20);
     }();
     if (s.n_cu == 0) HIP_CHECK(hipDeviceGetAttribute(&s.n_cu, hipDeviceAttributeMultiprocessorCount, s.device));
     uint32_t batch = o.sample_batch ? o.sample_batch : p.samples;

@@ -49,7 +49,6 @@ template <bool COUNT, class LeafFn>
 PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_scale, float& limit,
                       LocalCtr& lc, LeafFn&& leaf) {
     const float oa[3] = {o.x, o.y, o.z};
-    const float da[3] = {d.x, d.y, d.z};
     const float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     // clip against the (padded) scene bounds
     float tmin = t_start, tmax = INFINITY;
@@ -77,11 +76,13 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
         uint32_t axis = nd.y & 3u;
         if (axis != 3u) {
             float split = __uint_as_float(nd.x);
-            float oax = axis == 0 ? oa[0] : (axis == 1 ? oa[1] : oa[2]);
-            float dax = axis == 0 ? da[0] : (axis == 1 ? da[1] : da[2]);
-            float iax = axis == 0 ? inv[0] : (axis == 1 ? inv[1] : inv[2]);
-            float tplane = (split - oax) * iax;
-            bool below_first = (oax < split) || (oax == split && dax <= 0.f);
+            // select by value, not by operand (see pt_wavefront.h trav_step)
+            float tp0 = (split - o.x) * inv[0], tp1 = (split - o.y) * inv[1], tp2 = (split - o.z) * inv[2];
+            bool bf0 = (o.x < split) || (o.x == split && d.x <= 0.f);
+            bool bf1 = (o.y < split) || (o.y == split && d.y <= 0.f);
+            bool bf2 = (o.z < split) || (o.z == split && d.z <= 0.f);
+            float tplane = axis == 0 ? tp0 : (axis == 1 ? tp1 : tp2);
+            bool below_first = axis == 0 ? bf0 : (axis == 1 ? bf1 : bf2);
             uint32_t below = node + 1, above = nd.y >> 2;
             uint32_t first = below_first ? below : above;
             uint32_t second = below_first ? above : below;

@@ -143,6 +143,9 @@ PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursor, uint32_t n, bool need,
 // ---------------------------------------------------------------------------
 #define WF_LDS_STACK 8
 #define WF_THREADS 256
+#ifndef WF_MIN_WAVES
+#define WF_MIN_WAVES 1   // minimum waves per SIMD the trace/shadow kernels are compiled for
+#endif
 
 struct Trav {
     f3 o, d, inv;
@@ -222,11 +225,15 @@ PT_D int trav_step(const DevScene& S, Trav& T, const TravStack& st, float limit,
     uint32_t axis = nd.y & 3u;
     if (axis != 3u) {
         float split = __uint_as_float(nd.x);
-        float oax = axis == 0 ? T.o.x : (axis == 1 ? T.o.y : T.o.z);
-        float dax = axis == 0 ? T.d.x : (axis == 1 ? T.d.y : T.d.z);
-        float iax = axis == 0 ? T.inv.x : (axis == 1 ? T.inv.y : T.inv.z);
-        float tplane = (split - oax) * iax;
-        bool below_first = (oax < split) || (oax == split && dax <= 0.f);
+        // The per-axis quantities are computed for all three axes and selected by VALUE: selecting
+        // the operands (axis == 0 ? o.x : ...) makes the compiler keep o/d/inv in a scratch array
+        // and index it dynamically — three dependent scratch loads on every node step.
+        float tp0 = (split - T.o.x) * T.inv.x, tp1 = (split - T.o.y) * T.inv.y, tp2 = (split - T.o.z) * T.inv.z;
+        bool bf0 = (T.o.x < split) || (T.o.x == split && T.d.x <= 0.f);
+        bool bf1 = (T.o.y < split) || (T.o.y == split && T.d.y <= 0.f);
+        bool bf2 = (T.o.z < split) || (T.o.z == split && T.d.z <= 0.f);
+        float tplane = axis == 0 ? tp0 : (axis == 1 ? tp1 : tp2);
+        bool below_first = axis == 0 ? bf0 : (axis == 1 ? bf1 : bf2);
         uint32_t below = T.node + 1, above = nd.y >> 2;
         uint32_t first = below_first ? below : above;
         uint32_t second = below_first ? above : below;
@@ -392,7 +399,7 @@ PT_D float wf_draw(const DevScene& S, const WfParams& W, const uint32_t* __restr
 //   phase B  the parked lanes run Möller–Trumbore over their leaves together, then pop
 // ---------------------------------------------------------------------------
 template <bool ALPHA, bool COUNT>
-__global__ __launch_bounds__(WF_THREADS) void k_wf_trace(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
+__global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
                                                          const uint32_t* __restrict__ rng_blocks,
                                                          float4* __restrict__ queue, uint4* __restrict__ hits,
                                                          WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
@@ -661,7 +668,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
 // k_wf_trace; a job is one shaded surface, its lights are cast one after the other.
 // ---------------------------------------------------------------------------
 template <bool ALPHA, bool COUNT>
-__global__ __launch_bounds__(WF_THREADS) void k_wf_shadow(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
+__global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
                                                           const float4* __restrict__ contrib,
                                                           float4* __restrict__ queue_next, float* __restrict__ staging,
                                                           WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
