@@ -105,13 +105,17 @@ def main():
     image = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    kernel_ms, launches = [0.0], [0]
+    stage_ms = {k: 0.0 for k in ("generate_ms", "trace_ms", "shade_ms", "shadow_ms", "accumulate_ms", "postprocess_ms",
+                                 "integrate_ms", "total_ms")}
+    launches = {"launches": 0, "stage_launches": 0}
 
     def step():
         gscene.render_device(prof, opts, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
-        tm = gscene.timing()
-        kernel_ms[0] += tm.integrate_ms
-        launches[0] += tm.launches
+        tm = gscene.timing().as_dict()
+        for k in stage_ms:
+            stage_ms[k] += tm[k]
+        for k in launches:
+            launches[k] += tm[k]
         if world > 1:
             dist.all_gather_into_tensor(gathered, rgb_local)
             pta.check_gpu(lib.pt_assemble_tiles(C.byref(prof), world, tile, tile, slice_pixels, 3,
@@ -124,7 +128,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    kernel_ms[0], launches[0] = 0.0, 0
+    for k in stage_ms:
+        stage_ms[k] = 0.0
+    for k in launches:
+        launches[k] = 0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -139,7 +146,9 @@ def main():
     total_samples = npix * args.spp * args.steps
     value = total_samples / elapsed / 1e6
 
-    # ---- roofline of the dominant kernel (k_render), rank 0's shard
+    # ---- roofline of the dominant kernel (k_wf_trace: closest-hit ray casts), this rank's shard.
+    # Algorithmic bytes per closest-hit cast (SURVEY §8-d terms that belong to this kernel): the 64 B ray
+    # record read + 16 B hit record written, 8 B per KD node visited, 36 B per primitive tested.
     roofline = None
     counters = None
     if not args.no_counters:
@@ -149,9 +158,14 @@ def main():
         torch.cuda.synchronize()
         counters = gscene.counters().as_dict()
         floor_b, ceil_b, per = bytes_per_sample(counters, args.spp)
-        avg_ms = kernel_ms[0] / max(1, launches[0])
-        samples_per_launch = n_local * args.spp / max(1, launches[0] // args.steps)
-        achieved = ceil_b * samples_per_launch / (avg_ms * 1e-3) / 1e9
+        n_launch = max(1, launches["launches"])
+        avg_ms = stage_ms["integrate_ms"] / n_launch            # HIP events around every k_wf_trace launch
+        trace_bytes = counters["segments"] * 80 + counters["trace_nodes"] * 8 + counters["trace_tris"] * 36
+        bytes_per_launch = trace_bytes / max(1, n_launch // args.steps)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        kernel_total = sum(stage_ms[k] for k in ("generate_ms", "trace_ms", "shade_ms", "shadow_ms", "accumulate_ms",
+                                                 "postprocess_ms")) / args.steps
+        pipeline = ceil_b * n_local * args.spp / (kernel_total * 1e-3) / 1e9
         traffic = None
         tf = ROOT / "profiles" / "latest_traffic.json"
         if tf.exists():
@@ -161,11 +175,17 @@ def main():
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "k_wf_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_sample": round(ceil_b, 1),
-                    "queue_floor_bytes_per_sample": round(floor_b, 1),
-                    "queue_floor_frac": round(floor_b * samples_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_launch // args.steps,
+                    "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                    "pipeline": {"algorithmic_bytes_per_sample": round(ceil_b, 1),
+                                 "queue_floor_bytes_per_sample": round(floor_b, 1),
+                                 "kernel_ms_per_step": round(kernel_total, 3),
+                                 "achieved_GBps": round(pipeline, 1), "frac": round(pipeline / HBM_PEAK_GBS, 5),
+                                 "queue_floor_frac": round(floor_b * n_local * args.spp / (kernel_total * 1e-3) / 1e9
+                                                           / HBM_PEAK_GBS, 5)},
+                    "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
                     "per_sample": {k: round(v, 3) for k, v in per.items()}}
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only)
@@ -173,23 +193,23 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         oracle = entry.load_oracle()
         osc = oracle.OracleScene(scene.desc, oracle.PTO_BVH)
-        rows_per_band, n_bands = 2, 12
-        done, t_cpu = 0, 0.0
-        bands = []
-        for b in range(n_bands):
-            y0 = int((b + 0.5) * args.height / n_bands)
-            begin, end = y0 * args.width, min(npix, (y0 + rows_per_band) * args.width)
+        rows_per_band = 2
+        done, t_cpu, n_bands = 0, 0.0, 0
+        # 2-row bands at low-discrepancy rows over the whole frame until the time budget is used
+        while t_cpu < args.cpu_seconds and n_bands < args.height // rows_per_band:
+            y0 = int(((n_bands * 0.6180339887498949) % 1.0) * (args.height - rows_per_band))
+            begin, end = y0 * args.width, (y0 + rows_per_band) * args.width
             t1 = time.perf_counter()
             osc.render(prof, begin, end, 0)
             t_cpu += time.perf_counter() - t1
             done += (end - begin) * args.spp
-            bands.append(y0)
-            if t_cpu > args.cpu_seconds:
-                break
-        cpu = {"value": round(done / t_cpu / 1e6, 4), "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "port",
-               "sample": f"{len(bands)} bands of {rows_per_band} rows spread over the frame "
-                         f"({done} of {npix * args.spp} samples, {t_cpu:.1f} s), oracle/pt_oracle.cpp with its "
-                         f"AABB-tree candidate filter, OpenMP on all host cores"}
+            n_bands += 1
+        cpu = {"value": round(done / t_cpu / 1e6, 4), "unit": "Msamples/s", "cores": oracle.max_threads(),
+               "kind": "port",
+               "sample": f"{n_bands} bands of {rows_per_band} rows at golden-ratio rows over the frame "
+                         f"({done} of {npix * args.spp} samples, {t_cpu:.1f} s); oracle/pt_oracle.cpp (CPU restatement "
+                         f"of the reference algorithm, AABB-tree candidate filter), OpenMP threads = cores; "
+                         f"host reports {os.cpu_count()} logical CPUs"}
 
     if args.save_png and rank == 0:
         img = (image if world > 1 else rgb_local[: npix * 3]).cpu().numpy()

@@ -240,6 +240,8 @@ typedef struct pt_counters {
     uint64_t restarts;        /* alpha-walk continuation casts         */
     uint64_t max_nodes_per_cast;   /* longest single KD walk (wavefront integrator) */
     uint64_t casts_over_1k_nodes;
+    uint64_t trace_nodes;          /* share of nodes_visited / tris_tested spent in  */
+    uint64_t trace_tris;           /* closest-hit casts (the rest: shadow casts)      */
 } pt_counters;
 
 int pt_get_timing(const pt_scene* scene, pt_timing* out);

@@ -33,9 +33,14 @@ def lib():
         L.pto_rng_words.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
         L.pto_eval_math.argtypes = [C.c_int, vp, C.c_uint64, vp]
         L.pto_primary_ray.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp]
+        L.pto_max_threads.restype = C.c_int
         L.pto_last_error.restype = C.c_char_p
         _lib = L
     return _lib
+
+
+def max_threads():
+    return int(lib().pto_max_threads())
 
 
 def _check(rc):

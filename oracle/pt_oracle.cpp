@@ -849,6 +849,8 @@ extern "C" {
 
 const char* pto_last_error(void) { return g_err.c_str(); }
 
+int pto_max_threads(void) { return omp_get_max_threads(); }
+
 int pto_scene_create(const pt_scene_desc* desc, int mode, pto_scene** out) {
     if (!desc || !out) return set_err(PT_ERR_INVALID, "pto_scene_create: null argument");
     pto_scene* s = new pto_scene();

@@ -71,6 +71,9 @@ int pto_eval_math(int fn, const float* x, uint64_t n, float* out);
 int pto_primary_ray(const pto_scene* s, const pt_profile* profile, uint64_t pixel, uint32_t sample,
                     float* out6);
 
+/* OpenMP threads pto_render uses for threads <= 0. */
+int pto_max_threads(void);
+
 const char* pto_last_error(void);
 
 #ifdef __cplusplus

@@ -74,5 +74,5 @@ struct RenderParams {
 // Work counters (PT_FLAG_COUNTERS variant only).
 struct DevCounters {
     unsigned long long samples, segments, shadow_rays, nodes_visited, tris_tested, shaded_hits, rng_draws,
-        restarts, max_nodes_per_cast, casts_over_1k_nodes;
+        restarts, max_nodes_per_cast, casts_over_1k_nodes, trace_nodes, trace_tris;
 };

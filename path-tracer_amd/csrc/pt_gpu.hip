@@ -909,7 +909,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         DevCounters c;
         HIP_CHECK(hipMemcpy(&c, s.counter_buf.p, sizeof c, hipMemcpyDeviceToHost));
         s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
-                                 c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes};
+                                 c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes,
+                                 c.trace_nodes, c.trace_tris};
     }
 }
 

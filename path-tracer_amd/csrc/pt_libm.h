@@ -1,8 +1,214 @@
-// Device libm used by the integrator (see pt_math.h).
+// Device libm of the integrator: bit-exact restatements of the glibc 2.35 routines the
+// reference reaches through Rust's std (f32::acos / sin / cos / powf -> libm).
+//
+// Why: the reference image is a function of glibc's results (a 1-ulp change flips
+// pixels).  ocml's acosf/sinf/cosf/powf are accurate but not identical, which made ~1-7 % of the
+// pixels differ in the last bits and a few paths diverge.  With these routines the GPU image is
+// bit-identical to the CPU oracle, so the reference's own golden SHA-1 hashes can be asserted on
+// the GPU render (tests/test_gpu_parity.py).
+//
+// Algorithms (third-party, not in /root/reference; pinned by exhaustive comparison against the
+// container's libm.so.6, see tools/libm_probe.cpp and profiles/r01_libm_exhaustive.txt):
+//   sinf, cosf  glibc sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h, s_sincosf_data.c
+//               (ARM optimized-routines): double-precision reduction by pi/2 and two degree-7/8
+//               polynomials.  0 mismatches on every float in [0, 7].
+//   acosf       glibc sysdeps/ieee754/flt-32/e_acosf.c (fdlibm, pure f32).  0 mismatches on
+//               every float in [-1, 1].
+//   powf        glibc sysdeps/ieee754/flt-32/e_powf.c + e_powf_log2_data.c + e_exp2f_data.c:
+//               log2 via a 16-entry table and a degree-5 polynomial, exp2 via a 32-entry table,
+//               all in double.  x86-64 glibc dispatches to its FMA build; the one contraction
+//               that is observable is r = fma(z, invc, -1) (found by searching all 512
+//               placements): with it, 0 mismatches on every positive float for y = 1/2.2f and
+//               for y = 2.2f on [0, 1].
+// The file is compiled with -ffp-contract=off; the single fused operation is written explicitly.
 #pragma once
 
-PT_D float pt_acosf(float x) { return acosf(x); }
-PT_D float pt_sinf(float x) { return sinf(x); }
-PT_D float pt_cosf(float x) { return cosf(x); }
+PT_D uint32_t ptm_asuint(float f) { return __float_as_uint(f); }
+PT_D float ptm_asfloat(uint32_t u) { return __uint_as_float(u); }
+PT_D uint64_t ptm_asuint64(double d) { return (uint64_t)__double_as_longlong(d); }
+PT_D double ptm_asdouble(uint64_t u) { return __longlong_as_double((long long)u); }
+
+// ------------------------------------------------------------------ sinf / cosf
+struct PtmSincos {
+    double c0, c1, c2, c3, c4, s1, s2, s3;
+};
+PT_D uint32_t ptm_abstop12(float x) { return (ptm_asuint(x) >> 20) & 0x7ffu; }
+
+// sinf_poly of s_sincosf.h; `neg` selects __sincosf_table[1] (the negated cosine polynomial)
+PT_D float ptm_sinf_poly(double x, double x2, bool neg, int n) {
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10,
+                 c4 = 0x1.99343027bf8c3p-16, s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7,
+                 s3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double t1 = s2 + x2 * s3;
+        double x7 = x3 * x2;
+        double s = x + x3 * s1;
+        return (float)(s + x7 * t1);
+    }
+    const double k0 = neg ? -c0 : c0, k1 = neg ? -c1 : c1, k2 = neg ? -c2 : c2, k3 = neg ? -c3 : c3,
+                 k4 = neg ? -c4 : c4;
+    double x4 = x2 * x2;
+    double p2 = k3 + x2 * k4;
+    double p1 = k0 + x2 * k1;
+    double x6 = x4 * x2;
+    double c = p1 + x4 * k2;
+    return (float)(c + x6 * p2);
+}
+
+// reduce_fast: x - n*pi/2 with n = round(x * 2/pi) taken from a 2^24-scaled product
+PT_D double ptm_reduce_fast(double x, int& n) {
+    double r = x * 0x1.45F306DC9C883p+23;
+    n = ((int32_t)r + 0x800000) >> 24;
+    return x - (double)n * 0x1.921FB54442D18p0;
+}
+
+// |y| < 120 only (the integrator passes theta in [0, pi/2] and phi in [0, 2 pi)); larger
+// arguments and non-finite ones return NaN instead of taking glibc's reduce_large path.
+PT_D float pt_sinf(float y) {
+    double x = (double)y;
+    if (ptm_abstop12(y) < ptm_abstop12(0x1.921FB6p-1f)) {
+        double s = x * x;
+        if (ptm_abstop12(y) < ptm_abstop12(0x1p-12f)) return y;
+        return ptm_sinf_poly(x, s, false, 0);
+    }
+    if (ptm_abstop12(y) < ptm_abstop12(120.0f)) {
+        int n;
+        x = ptm_reduce_fast(x, n);
+        double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;  // sign[] = {1, -1, -1, 1}
+        return ptm_sinf_poly(x * s, x * x, (n & 2) != 0, n);
+    }
+    return __uint_as_float(0x7fc00000u);
+}
+
+PT_D float pt_cosf(float y) {
+    double x = (double)y;
+    if (ptm_abstop12(y) < ptm_abstop12(0x1.921FB6p-1f)) {
+        double x2 = x * x;
+        if (ptm_abstop12(y) < ptm_abstop12(0x1p-12f)) return 1.0f;
+        return ptm_sinf_poly(x, x2, false, 1);
+    }
+    if (ptm_abstop12(y) < ptm_abstop12(120.0f)) {
+        int n;
+        x = ptm_reduce_fast(x, n);
+        double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        return ptm_sinf_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
+    }
+    return __uint_as_float(0x7fc00000u);
+}
+
+// ------------------------------------------------------------------ acosf
+PT_D float pt_acosf(float x) {
+    const float one = 1.0f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f,
+                pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+                pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f, qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f,
+                qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    int32_t hx = (int32_t)ptm_asuint(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) {
+        if (hx > 0) return 0.0f;
+        return pi + 2.0f * pio2_lo;
+    }
+    if (ix > 0x3f800000) return (x - x) / (x - x);
+    if (ix < 0x3f000000) {  // |x| < 0.5
+        if (ix <= 0x23000000) return pio2_hi + pio2_lo;
+        float z = x * x;
+        float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        float r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (hx < 0) {  // x < -0.5
+        float z = (one + x) * 0.5f;
+        float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        float s = sqrtf(z);
+        float r = p / q;
+        float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    float z = (one - x) * 0.5f;  // x > 0.5
+    float s = sqrtf(z);
+    float df = ptm_asfloat(ptm_asuint(s) & 0xfffff000u);
+    float c = (z - df * df) / (s + df);
+    float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    float r = p / q;
+    float w = r * s + c;
+    return 2.0f * (df + w);
+}
+
+// ------------------------------------------------------------------ powf
+__device__ const double ptm_log2_tab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+__device__ const unsigned long long ptm_exp2_tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+// powf(x, y) for a finite, positive, non-integer y with |y * log2(x)| < 126 (the integrator
+// only calls it with y = 1/2.2f: Renderer::post_processing, renderer/mod.rs:339-345).
+PT_D float pt_powf_pos_y(float x, float y) {
+    uint32_t ix = ptm_asuint(x);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (2u * ix == 0u || 2u * ix >= 2u * 0x7f800000u) {  // zero, inf, nan
+            if (2u * ix > 2u * 0x7f800000u) return x + y;
+            return x * x;
+        }
+        if (ix & 0x80000000u) return (x - x) / (x - x);  // finite x < 0: invalid
+        if (ix < 0x00800000u) {                           // subnormal: normalise
+            ix = ptm_asuint(x * 0x1p23f);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
+    }
+    // log2_inline
+    uint32_t tmp = ix - 0x3f330000u;
+    int i = (int)((tmp >> (23 - 4)) % 16u);
+    uint32_t top = tmp & 0xff800000u;
+    uint32_t iz = ix - top;
+    int k = (int32_t)top >> 23;
+    double invc = ptm_log2_tab[i][0], logc = ptm_log2_tab[i][1];
+    double z = (double)ptm_asfloat(iz);
+    double r = __builtin_fma(z, invc, -1.0);  // the one contraction of glibc's FMA build that shows
+    double y0 = logc + (double)k;
+    const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
+                 A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
+    double r2 = r * r;
+    double yy = A0 * r + A1;
+    double p = A2 * r + A3;
+    double r4 = r2 * r2;
+    double q = A4 * r + y0;
+    q = p * r2 + q;
+    yy = yy * r4 + q;
+    double xd = (double)y * yy;
+    // exp2_inline
+    const double SHIFT = 0x1.8p+52 / 32.0;
+    double kd = xd + SHIFT;
+    uint64_t ki = ptm_asuint64(kd);
+    kd -= SHIFT;
+    double rr = xd - kd;
+    uint64_t t = ptm_exp2_tab[ki % 32u];
+    t += ki << (52 - 5);
+    double s = ptm_asdouble(t);
+    const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+    double zz = C0 * rr + C1;
+    double rr2 = rr * rr;
+    double v = C2 * rr + 1.0;
+    v = zz * rr2 + v;
+    v = v * s;
+    return (float)v;
+}
+
 // powf(x, 1/2.2f) of Renderer::post_processing (renderer/mod.rs:339-345)
-PT_D float pt_pow_inv_gamma(float x) { return powf(x, 1.0f / 2.2f); }
+PT_D float pt_pow_inv_gamma(float x) { return pt_powf_pos_y(x, 1.0f / 2.2f); }

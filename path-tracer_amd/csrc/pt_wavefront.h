@@ -529,6 +529,8 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
         atomicAdd(&gctr->nodes_visited, (unsigned long long)lc.nodes);
         atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
         atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
+        atomicAdd(&gctr->trace_nodes, (unsigned long long)lc.nodes);
+        atomicAdd(&gctr->trace_tris, (unsigned long long)lc.tris);
         if (ALPHA) atomicAdd(&gctr->shaded_hits, (unsigned long long)lc.shaded);
         if (ALPHA) atomicAdd(&gctr->rng_draws, (unsigned long long)lc.shadow_rays);
     }
