@@ -753,7 +753,6 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             s.trace_blocks = std::max(1, alpha ? b : a) * s.n_cu;
             s.shadow_blocks = std::max(1, alpha ? d : c) * s.n_cu;
         }
-        s.rng_buf.ensure((size_t)cap * 64u);
         s.wf_queue[0].ensure((size_t)cap * 64u);
         s.wf_queue[1].ensure((size_t)cap * 64u);
         s.wf_hits.ensure((size_t)cap * 16u);
@@ -823,14 +822,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 HIP_CHECK(hipMemsetAsync(wctr, 0, sizeof(WfCounters) * (p.bounces + 3), stream));
                 stage_begin(0);
                 hipLaunchKernelGGL(k_wf_generate, dim3((W.n_items + 255u) / 256u), dim3(256), 0, stream, s.dev, W, d_tiles,
-                                   (uint32_t*)s.rng_buf.p, (float4*)s.wf_queue[0].p, wctr, gctr);
+                                   (float4*)s.wf_queue[0].p, wctr, gctr);
                 HIP_CHECK(hipGetLastError());
                 stage_end();
                 for (uint32_t b = 0; b <= p.bounces; ++b) {
                     W.bounce = b;
                     float4* q_in = (float4*)s.wf_queue[b & 1].p;
                     float4* q_out = (float4*)s.wf_queue[(b + 1) & 1].p;
-                    const uint32_t* rngb = (const uint32_t*)s.rng_buf.p;
 #define PT_LAUNCH_AC(kernel, grid, ...)                                                                         \
     do {                                                                                                        \
         if (alpha && counting) hipLaunchKernelGGL((kernel<true, true>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);    \
@@ -848,12 +846,12 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         HIP_CHECK(hipGetLastError());                                                                           \
     } while (0)
                     stage_begin(1);
-                    PT_LAUNCH_AC(k_wf_trace, s.trace_blocks, s.dev, W, d_tiles, rngb, q_in, (uint4*)s.wf_hits.p, wctr, gctr);
+                    PT_LAUNCH_AC(k_wf_trace, s.trace_blocks, s.dev, W, q_in, (uint4*)s.wf_hits.p, wctr, gctr);
                     stage_end();
                     ++launches;
                     stage_begin(2);
                     // PT_LAUNCH_AC launches 256-thread workgroups; the shade kernel wants WF_SHADE_THREADS
-                    PT_LAUNCH_SHADE(k_wf_shade, (uint32_t)(s.n_cu * 4), s.dev, W, d_tiles, rngb, (const float4*)q_in,
+                    PT_LAUNCH_SHADE(k_wf_shade, (uint32_t)(s.n_cu * 4), s.dev, W, (const float4*)q_in,
                                  (const uint4*)s.wf_hits.p, q_out, (float4*)s.wf_shadow.p, (float4*)s.wf_contrib.p,
                                  (float*)s.staging_buf.p, wctr, gctr);
                     stage_end();

@@ -4,7 +4,7 @@
 // other inside one fused kernel (measured: 8 of 64 lanes active per VALU instruction there).
 //
 //   per chunk of work items (one item = one path sample, pt_gpu.hip decode_item):
-//     k_wf_generate                 ChaCha12 block + camera ray            -> queue[0]
+//     k_wf_generate                 ChaCha12 block (words 0,1) + camera ray -> queue[0]
 //     for bounce = 0 .. bounces:
 //        k_wf_trace   (persistent)  ray_cast + alpha walk                   -> hit[i]
 //        k_wf_shade                 material, BRDF, next ray, termination   -> queue[b+1], shadow queue
@@ -13,7 +13,7 @@
 //
 // Queue records are 16-byte vectors read and written by consecutive lanes (coalesced):
 //   PathRec  64 B  q0 = (o.xyz, d.x)  q1 = (d.yz, thr.xy)  q2 = (thr.z, color.xyz)
-//                  q3 = (item_rel, draw_idx | bounce << 16, out_slot, item_abs)
+//                  q3 = (seed_lo, draw_idx | bounce << 16, out_slot, seed_hi)   seed = StdRng seed of the sample
 //   HitRec   16 B  (pid | flags << 28 ... see pack_hit, key, u, v)
 //   ShadowRec 64 B s0 = (pos.xyz, gn.x) s1 = (gn.yz, uv.xy) s2 = (color.xyz, bits(next_index))
 //                  s3 = (bits(out_slot), bits(flags), 0, 0)     + contrib[light][k] float4
@@ -331,11 +331,14 @@ PT_D bool unpack_hit(uint4 r, RawHit& h) {
 // generate: RNG block + camera ray for every valid item of the chunk
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wf_generate(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
-                                                     uint32_t* __restrict__ rng_blocks, float4* __restrict__ queue,
-                                                     WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
+                                                     float4* __restrict__ queue, WfCounters* __restrict__ ctr,
+                                                     DevCounters* __restrict__ gctr) {
     // No compaction here: queue[0] slot = item (the only invalid items are the 8x8 blocks that
     // hang over the image border); an invalid item is a record with out_slot = ~0 that the
     // trace kernel answers with "no hit" and the shade kernel drops.
+    // The ChaCha block is NOT staged: 64 B per item was half of this kernel's HBM traffic, while
+    // a path uses 3 words on average.  The consumers (shade, alpha walk) are memory-bound and
+    // re-derive the block from the 64-bit seed carried in the record (~700 integer ops).
     uint32_t rel = blockIdx.x * 256u + threadIdx.x;
     if (rel == 0) ctr[0].queue_count = W.n_items;
     if (rel >= W.n_items) return;
@@ -345,8 +348,7 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevScene S, WfParams W, con
         q[0] = make_float4(0.f, 0.f, 0.f, 0.f);
         q[1] = make_float4(0.f, 0.f, 0.f, 0.f);
         q[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        q[3] = make_float4(__uint_as_float(rel), __uint_as_float(2u), __uint_as_float(0xffffffffu),
-                           __uint_as_float(W.item_base + rel));
+        q[3] = make_float4(0.f, __uint_as_float(2u), __uint_as_float(0xffffffffu), 0.f);
         return;
     }
     if (gctr) {
@@ -356,8 +358,6 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevScene S, WfParams W, con
     uint32_t w[16];
     uint64_t seed = (uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples;
     pt_chacha12_block(seed, 0u, w);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) rng_blocks[(size_t)i * W.cap + rel] = w[i];
     float r1 = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
     float r2 = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
     f3 o, d;
@@ -366,25 +366,29 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevScene S, WfParams W, con
     q[0] = make_float4(o.x, o.y, o.z, d.x);
     q[1] = make_float4(d.y, d.z, 1.f, 1.f);
     q[2] = make_float4(1.f, 0.f, 0.f, 0.f);
-    q[3] = make_float4(__uint_as_float(rel), __uint_as_float(2u), __uint_as_float(out_slot),
-                       __uint_as_float(W.item_base + rel));
+    q[3] = make_float4(__uint_as_float((uint32_t)seed), __uint_as_float(2u), __uint_as_float(out_slot),
+                       __uint_as_float((uint32_t)(seed >> 32)));
 }
 
-// rng.gen::<f32>() number idx of the item (first block staged by k_wf_generate).
-PT_D float wf_draw(const DevScene& S, const WfParams& W, const uint32_t* __restrict__ tile_offsets,
-                   const uint32_t* __restrict__ rng_blocks, uint32_t item_rel, uint32_t item_abs, uint32_t idx) {
-    uint32_t word;
-    if (idx < 16u) {
-        word = rng_blocks[(size_t)idx * W.cap + item_rel];
-    } else {
-        ItemRef it = decode_item(W.P, tile_offsets, item_abs);
-        uint64_t seed = (uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples;
-        uint32_t w[16];
-        pt_chacha12_block(seed, idx >> 4, w);
-        word = w[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) word = (idx & 15u) == (uint32_t)i ? w[i] : word;
+// Sequential draws of one path inside one kernel invocation: rng.gen::<f32>() number idx, idx + 1, ...
+// The ChaCha block holding idx is derived from the seed on first use and kept in registers.
+struct WfRng {
+    uint64_t seed;
+    uint32_t block;      // index of the block held in w (0xffffffff = none)
+    uint32_t w[16];
+};
+PT_D void wf_rng_init(WfRng& r, uint32_t seed_lo, uint32_t seed_hi) {
+    r.seed = ((uint64_t)seed_hi << 32) | seed_lo;
+    r.block = 0xffffffffu;
+}
+PT_D float wf_rng_draw(WfRng& r, uint32_t idx) {
+    if ((idx >> 4) != r.block) {
+        r.block = idx >> 4;
+        pt_chacha12_block(r.seed, r.block, r.w);
     }
+    uint32_t word = r.w[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) word = (idx & 15u) == (uint32_t)i ? r.w[i] : word;
     return (float)(word >> 8) * (1.0f / 16777216.0f);
 }
 
@@ -399,8 +403,7 @@ PT_D float wf_draw(const DevScene& S, const WfParams& W, const uint32_t* __restr
 //   phase B  the parked lanes run Möller–Trumbore over their leaves together, then pop
 // ---------------------------------------------------------------------------
 template <bool ALPHA, bool COUNT>
-__global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
-                                                         const uint32_t* __restrict__ rng_blocks,
+__global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W,
                                                          float4* __restrict__ queue, uint4* __restrict__ hits,
                                                          WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     __shared__ uint2 lds_stack[WF_LDS_STACK * WF_THREADS];
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
     RawHit best, kept;       // kept: the last surface of the alpha walk when every hit was skipped
     bool have_kept = false;
     float t_prev = -INFINITY;
-    uint32_t ord_prev = 0, idx = 0, item_rel = 0, item_abs = 0, draw = 0;
+    uint32_t ord_prev = 0, idx = 0, seed_lo = 0, seed_hi = 0, draw = 0;
     bool active = false, exhausted = false, at_leaf = false, cast_done = false;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     uint32_t cast_nodes0 = 0;
@@ -432,7 +435,9 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
             if (COUNT) lc.shaded++;
             bool stop = opacity >= 1.f;
             if (!stop && opacity > 0.001f) {
-                float r = wf_draw(S, W, tile_offsets, rng_blocks, item_rel, item_abs, draw++);
+                WfRng rng;   // rare path (translucent surfaces only): block re-derived per draw
+                wf_rng_init(rng, seed_lo, seed_hi);
+                float r = wf_rng_draw(rng, draw++);
                 stop = r < opacity;
                 if (COUNT) lc.shadow_rays++;  // (re-used as the alpha-draw counter in this kernel)
             }
@@ -484,9 +489,9 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
                 f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
                 const bool valid_item = __float_as_uint(q3.z) != 0xffffffffu;
                 if (ALPHA) {
-                    item_rel = __float_as_uint(q3.x);
+                    seed_lo = __float_as_uint(q3.x);
                     draw = __float_as_uint(q3.y) & 0xffffu;
-                    item_abs = __float_as_uint(q3.w);
+                    seed_hi = __float_as_uint(q3.w);
                 }
                 if (COUNT && valid_item) lc.segments++;
                 if (COUNT) cast_nodes0 = lc.nodes;
@@ -541,8 +546,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
 // ---------------------------------------------------------------------------
 #define WF_SHADE_THREADS 512
 template <bool ALPHA, bool COUNT>
-__global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
-                                                  const uint32_t* __restrict__ rng_blocks,
+__global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfParams W,
                                                   const float4* __restrict__ queue_in, const uint4* __restrict__ hits,
                                                   float4* __restrict__ queue_out, float4* __restrict__ shadow_q,
                                                   float4* __restrict__ contrib, float* __restrict__ staging,
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
     uint32_t i = base + threadIdx.x;
     bool live = i < n;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), color = mk3(0, 0, 0);
-    uint32_t item_rel = 0, item_abs = 0, draw = 0, out_slot = 0;
+    uint32_t seed_lo = 0, seed_hi = 0, draw = 0, out_slot = 0;
     RawHit h;
     bool hit = false;
     if (live) {
@@ -568,10 +572,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         d = mk3(q0.w, q1.x, q1.y);
         thr = mk3(q1.z, q1.w, q2.x);
         color = mk3(q2.y, q2.z, q2.w);
-        item_rel = __float_as_uint(q3.x);
+        seed_lo = __float_as_uint(q3.x);
         draw = __float_as_uint(q3.y) & 0xffffu;
         out_slot = __float_as_uint(q3.z);
-        item_abs = __float_as_uint(q3.w);
+        seed_hi = __float_as_uint(q3.w);
         hit = unpack_hit(hits[i], h);
         if (out_slot == 0xffffffffu) live = false;  // item outside the image (k_wf_generate)
     }
@@ -599,10 +603,12 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         color = color + mul_ew(thr, ms.emissive);
         to_shadow = true;
         bool ended = false;
+        WfRng rng;
+        wf_rng_init(rng, seed_lo, seed_hi);
         if (bounce < bounces) {
             next_o = surf.pos + surf.normal * 0.00001f;
-            float r1 = wf_draw(S, W, tile_offsets, rng_blocks, item_rel, item_abs, draw++);
-            float r2 = wf_draw(S, W, tile_offsets, rng_blocks, item_rel, item_abs, draw++);
+            float r1 = wf_rng_draw(rng, draw++);
+            float r2 = wf_rng_draw(rng, draw++);
             next_d = ct_sample(brdf, normal, view, r1, r2);
             f3 wgt = ct_eval_indirect(brdf, normal, view, next_d) / 1.0f;
             next_thr = mul_ew(thr, wgt);
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         if (!ended && bounce > 3) {
             float p = max_rs(max_rs(next_thr.x, next_thr.y), next_thr.z);
             next_thr = next_thr * (1.f / p);
-            if (wf_draw(S, W, tile_offsets, rng_blocks, item_rel, item_abs, draw++) > p) ended = true;
+            if (wf_rng_draw(rng, draw++) > p) ended = true;
         }
         survive = !ended && bounce + 1 <= bounces;
     }
@@ -642,8 +648,8 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         q[0] = make_float4(next_o.x, next_o.y, next_o.z, next_d.x);
         q[1] = make_float4(next_d.y, next_d.z, next_thr.x, next_thr.y);
         q[2] = make_float4(next_thr.z, color.x, color.y, color.z);  // colour is patched by k_wf_shadow
-        q[3] = make_float4(__uint_as_float(item_rel), __uint_as_float((draw & 0xffffu) | ((bounce + 1) << 16)),
-                           __uint_as_float(out_slot), __uint_as_float(item_abs));
+        q[3] = make_float4(__uint_as_float(seed_lo), __uint_as_float((draw & 0xffffu) | ((bounce + 1) << 16)),
+                           __uint_as_float(out_slot), __uint_as_float(seed_hi));
     }
     if (to_shadow) {
         float4* sq = shadow_q + (size_t)sh_idx * 4;
