@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-counters", action="store_true")
     ap.add_argument("--save-png", default=None)
+    ap.add_argument("--backend", default="nccl", help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                    "the N > 1 path with several ranks on ONE GPU: set PT_BENCH_DEVICE=0)")
     args = ap.parse_args()
 
     import numpy as np
@@ -70,13 +72,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if "PT_BENCH_DEVICE" in os.environ:  # rehearsal only: several ranks on one GPU (gloo backend)
+        local_rank = int(os.environ["PT_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective buffers live
 
     pta = entry.load_package()
     lib = pta.gpu_lib()
@@ -96,7 +104,7 @@ def main():
     npix = args.width * args.height
     slice_pixels = n_local
     if world > 1:
-        t = torch.tensor([n_local], device=dev, dtype=torch.int64)
+        t = torch.tensor([n_local], device=cdev, dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         slice_pixels = int(t.item())
     rgb_local = torch.zeros(slice_pixels * 3, dtype=torch.uint8, device=dev)
@@ -117,7 +125,12 @@ def main():
         for k in launches:
             launches[k] += tm[k]
         if world > 1:
-            dist.all_gather_into_tensor(gathered, rgb_local)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, rgb_local)   # RCCL over xGMI, one exchange per frame
+            else:
+                parts = [torch.empty(slice_pixels * 3, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, rgb_local.cpu())
+                gathered.copy_(torch.cat(parts))
             pta.check_gpu(lib.pt_assemble_tiles(C.byref(prof), world, tile, tile, slice_pixels, 3,
                                                 gathered.data_ptr(), image.data_ptr(), stream))
 
@@ -139,7 +152,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -211,6 +224,14 @@ def main():
                          f"of the reference algorithm, AABB-tree candidate filter), OpenMP threads = cores; "
                          f"host reports {os.cpu_count()} logical CPUs"}
 
+    if os.environ.get("PT_BENCH_CHECK") and world > 1:
+        # rehearsal check: the assembled frame equals an unsharded render on this rank
+        full = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
+        gscene.render_device(prof, pta.Opts.make(device=local_rank), full.data_ptr(), None, stream)
+        torch.cuda.synchronize()
+        if not torch.equal(full, image):
+            raise SystemExit(f"rank {rank}: assembled image differs from the unsharded render")
+        print(f"rank {rank}: assembled image == unsharded render", file=sys.stderr)
     if args.save_png and rank == 0:
         img = (image if world > 1 else rgb_local[: npix * 3]).cpu().numpy()
         pta.check_host(pta.host_lib().pth_png_write_rgb8(os.fsencode(args.save_png), args.width, args.height,

@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_cuda_first():
+    """On the GPU box torch must create its HIP context before libptgpu.so does, otherwise torch reports
+    'No HIP GPUs are available' in the same process (bench.py does the same)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def pta():
     return entry.load_package()

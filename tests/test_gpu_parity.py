@@ -200,6 +200,32 @@ def test_sharded_render_is_bit_identical(pta, scene_cache, gpu_scene_cache):
         assert seen.all()
 
 
+def test_assemble_tiles_rebuilds_the_frame(pta, gpu_scene_cache):
+    """pt_assemble_tiles: packed per-rank slices (as an all-gather delivers them) -> row-major image, u8 and f32."""
+    import torch
+    prof = pta.Profile.make(150, 70, 2, 2)
+    g = gpu_scene_cache("cube")
+    full_rgb, full_acc = g.render(prof)
+    for count, tile in ((2, 32), (3, 16), (5, 32)):
+        slices_rgb, slices_acc = [], []
+        for rank in range(count):
+            rgb, acc = g.render(prof, pta.Opts.make(shard_rank=rank, shard_count=count, tile_w=tile, tile_h=tile))
+            slices_rgb.append(rgb)
+            slices_acc.append(acc)
+        slice_pixels = max(len(r) for r in slices_rgb)
+        for slices, elem, dtype, full in ((slices_rgb, 3, np.uint8, full_rgb), (slices_acc, 12, np.float32, full_acc)):
+            packed = np.zeros((count, slice_pixels, 3), dtype)
+            for r, sl in enumerate(slices):
+                packed[r, : len(sl)] = sl
+            d_in = torch.from_numpy(packed.reshape(-1)).cuda()
+            d_out = torch.zeros(prof.width * prof.height * 3, dtype=d_in.dtype, device="cuda")
+            pta.check_gpu(pta.gpu_lib().pt_assemble_tiles(C.byref(prof), count, tile, tile, slice_pixels, elem,
+                                                          d_in.data_ptr(), d_out.data_ptr(), None))
+            torch.cuda.synchronize()
+            assert np.array_equal(d_out.cpu().numpy().reshape(-1, 3).view(np.uint32 if elem == 12 else np.uint8),
+                                  full.view(np.uint32 if elem == 12 else np.uint8))
+
+
 def test_sample_batches_keep_accumulation_order(pta, scene_cache, gpu_scene_cache):
     prof = pta.Profile.make(96, 64, 9, 2)
     g = gpu_scene_cache("cube")
