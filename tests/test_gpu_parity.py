@@ -262,6 +262,23 @@ def test_generated_scene_ray_cast(pta, oracle):
     assert ok >= 0.999 and u8_ok >= 0.999
 
 
+def test_translucent_generated_scene_is_bit_identical(pta, oracle):
+    """BASELINE config 5 ingredients at test size: opacity factor 0.5 + checker opacity texture on the shells
+    (alpha walk with RNG draws, ordered shadow attenuation), ACES tone-map, 8 bounces."""
+    scene = pta.HostScene.generate_ps5(12000, seed=0, flags=1)
+    g = pta.GpuScene(scene)
+    assert g.info().has_translucent == 1
+    prof = pta.Profile.make(192, 108, 8, 8, "ACES")
+    ok, u8_ok, exact, same_image = compare_render(pta, oracle, scene, g, prof)
+    assert exact == 1.0 and same_image
+    g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS))
+    c = g.counters().as_dict()
+    _, _, st = oracle.OracleScene(scene.desc, oracle.PTO_BVH).render(prof)
+    for k in ("samples", "segments", "shadow_rays", "shaded_hits", "rng_draws"):
+        assert c[k] == st[k], (k, c[k], st[k])
+    assert c["restarts"] > 0
+
+
 def test_host_buffer_errors(pta, scene_cache, gpu_scene_cache):
     g = gpu_scene_cache("cube")
     with pytest.raises(pta.PtError):
