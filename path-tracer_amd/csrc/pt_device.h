@@ -4,7 +4,9 @@
 // (288 GB HBM3E): the whole scene, KD-tree and textures are replicated on
 // every GPU.
 //
-//   kd_nodes    8 B / node   pbrt-style KD node (see include/pthost.h)
+//   kd_nodes    8 B / node   interior: (split, pair << 2 | axis), children = nodes pair and pair + 1;
+//               leaf: (first leaf record, n << 2 | 3).  Treelet order (4-level subtrees share a
+//               128-B line); the host builder's DFS array (include/pthost.h) is permuted on upload
 //   leaf_prims  48 B / leaf reference, stored leaf after leaf so a leaf's
 //               primitives are one contiguous, 16-B aligned run:
 //                 q0 = (v0.x, v0.y, v0.z, bits(prim_id | kind<<31))
@@ -75,4 +77,5 @@ struct RenderParams {
 struct DevCounters {
     unsigned long long samples, segments, shadow_rays, nodes_visited, tris_tested, shaded_hits, rng_draws,
         restarts, max_nodes_per_cast, casts_over_1k_nodes, trace_nodes, trace_tris;
+    unsigned long long stamps[8];  // diagnostic builds (-DWF_STAMPS) only
 };

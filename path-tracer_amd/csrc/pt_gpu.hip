@@ -600,8 +600,55 @@ void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
         lights[i]._pad = 0.f;
     }
 
+    // ---- device node layout.  The builder emits DFS order (below child = next node); on the GPU the
+    // walk is bound by cache-line round trips (a wave waits for the slowest of ~43 scattered node
+    // fetches), so the nodes are re-laid out in treelets: sibling PAIRS are adjacent (children of a
+    // node = pair, pair + 1) and the pairs of a 4-level subtree are packed consecutively, so that
+    // one 128-byte line serves up to four steps of a walk.  Node words: interior (split,
+    // pair << 2 | axis), leaf (first record, n << 2 | 3) as before.
+    std::vector<pth_kd_node> tre(std::max<uint64_t>(kd.n_nodes, 1) + 1);
+    {
+        const pth_kd_node* N = kd.nodes;
+        const int H = 4;  // treelet height: 2 + 4 + 8 = 14 nodes = 112 B below the treelet root pair
+        if (kd.n_nodes == 0) {
+            tre[0] = pth_kd_node{0u, 3u};
+        } else {
+            std::vector<uint32_t> new_index(kd.n_nodes, 0xffffffffu);
+            new_index[0] = 0;
+            uint32_t next = 2;  // pairs start at even indices; slot 1 pads the root
+            std::vector<uint32_t> cluster_roots{0}, frontier, level;
+            size_t cr = 0;
+            while (cr < cluster_roots.size()) {
+                level.assign(1, cluster_roots[cr++]);
+                for (int depth = 0; depth < H && !level.empty(); ++depth) {
+                    frontier.clear();
+                    for (uint32_t n : level) {
+                        if ((N[n].w1 & 3u) == 3u) continue;
+                        uint32_t below = n + 1, above = N[n].w1 >> 2;
+                        new_index[below] = next;
+                        new_index[above] = next + 1;
+                        next += 2;
+                        frontier.push_back(below);
+                        frontier.push_back(above);
+                    }
+                    level.swap(frontier);
+                }
+                // whatever is left at the bottom of this treelet starts new treelets
+                for (uint32_t n : level)
+                    if ((N[n].w1 & 3u) != 3u) cluster_roots.push_back(n);
+            }
+            if (next > tre.size()) tre.resize(next);
+            if (next >= (1u << 30)) fail(PT_ERR_UNSUPPORTED, "KD-tree has too many nodes");
+            for (uint64_t n = 0; n < kd.n_nodes; ++n) {
+                pth_kd_node nd = N[n];
+                if ((nd.w1 & 3u) != 3u) nd.w1 = (new_index[n + 1] << 2) | (nd.w1 & 3u);
+                tre[new_index[n]] = nd;
+            }
+            tre[1] = pth_kd_node{0u, 3u};
+        }
+    }
     DevScene& D = s.dev;
-    D.kd_nodes = (const uint2*)s.upload(kd.nodes, kd.n_nodes);
+    D.kd_nodes = (const uint2*)s.upload(tre.data(), tre.size());
     D.leaf_prims = s.upload(leaf.data(), leaf.size());
     D.prim_attr = s.upload(attr.data(), attr.size());
     D.prim_pos = s.upload(pos.data(), pos.size());
@@ -752,6 +799,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, k_wf_shadow<true, false>, 256, 0));
             s.trace_blocks = std::max(1, alpha ? b : a) * s.n_cu;
             s.shadow_blocks = std::max(1, alpha ? d : c) * s.n_cu;
+            if (const char* e = getenv("PT_WF_BLOCKS_PER_CU")) {  // experiments: fewer resident workgroups
+                int k = atoi(e);
+                if (k > 0) {
+                    s.trace_blocks = std::min(s.trace_blocks, k * s.n_cu);
+                    s.shadow_blocks = std::min(s.shadow_blocks, k * s.n_cu);
+                }
+            }
         }
         s.wf_queue[0].ensure((size_t)cap * 64u);
         s.wf_queue[1].ensure((size_t)cap * 64u);
@@ -909,6 +963,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
                                  c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes,
                                  c.trace_nodes, c.trace_tris};
+        if (getenv("PT_DEBUG_STAMPS"))
+            fprintf(stderr, "[pt] trace stamps: refill %llu walk %llu leaf %llu complete %llu cycles | walk lanes/step %.1f (%llu steps) | leaf lanes/run %.1f (%llu runs)\n",
+                    c.stamps[0], c.stamps[1], c.stamps[2], c.stamps[3], c.stamps[5] ? (double)c.stamps[4] / c.stamps[5] : 0.0,
+                    c.stamps[5], c.stamps[7] ? (double)c.stamps[6] / c.stamps[7] : 0.0, c.stamps[7]);
     }
 }
 

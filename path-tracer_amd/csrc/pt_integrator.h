@@ -83,7 +83,7 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
             bool bf2 = (o.z < split) || (o.z == split && d.z <= 0.f);
             float tplane = axis == 0 ? tp0 : (axis == 1 ? tp1 : tp2);
             bool below_first = axis == 0 ? bf0 : (axis == 1 ? bf1 : bf2);
-            uint32_t below = node + 1, above = nd.y >> 2;
+            uint32_t below = nd.y >> 2, above = below + 1;  // sibling pair (treelet layout, pt_gpu.hip)
             uint32_t first = below_first ? below : above;
             uint32_t second = below_first ? above : below;
             // A primitive touching the split plane lives on one side only (kd_build.cpp), so a

@@ -141,7 +141,9 @@ PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursor, uint32_t n, bool need,
 // overflow into a per-lane scratch array.  Almost all pushes stay within the LDS part, which
 // takes the stack traffic off the vector-memory path (it was 2 GB of HBM writes per 33 M rays).
 // ---------------------------------------------------------------------------
+#ifndef WF_LDS_STACK
 #define WF_LDS_STACK 8
+#endif
 #define WF_THREADS 256
 #ifndef WF_MIN_WAVES
 #define WF_MIN_WAVES 1   // minimum waves per SIMD the trace/shadow kernels are compiled for
@@ -161,6 +163,8 @@ struct TravStack {
     float* ov_tmax;
 };
 
+// The LDS part is always addressed as LDS and the (rare) overflow has its own branch: a merged
+// "pointer select" makes the compiler fall back to flat (generic) loads on the hot path.
 PT_D void stack_push(const TravStack& st, int sp, uint32_t node, float tmax) {
     if (sp < WF_LDS_STACK) {
         st.lds[sp * WF_THREADS] = make_uint2(node, __float_as_uint(tmax));
@@ -170,11 +174,11 @@ PT_D void stack_push(const TravStack& st, int sp, uint32_t node, float tmax) {
     }
 }
 PT_D void stack_get(const TravStack& st, int sp, uint32_t& node, float& tmax) {
-    if (sp < WF_LDS_STACK) {
-        uint2 e = st.lds[sp * WF_THREADS];
-        node = e.x;
-        tmax = __uint_as_float(e.y);
-    } else {
+    int slot = sp < WF_LDS_STACK ? sp : WF_LDS_STACK - 1;
+    uint2 e = st.lds[slot * WF_THREADS];
+    node = e.x;
+    tmax = __uint_as_float(e.y);
+    if (sp >= WF_LDS_STACK) {
         node = st.ov_node[sp - WF_LDS_STACK];
         tmax = st.ov_tmax[sp - WF_LDS_STACK];
     }
@@ -218,35 +222,37 @@ PT_D bool trav_pop(Trav& T, const TravStack& st, float limit) {
 }
 
 // One node.  Returns 0 = still walking, 1 = holding a non-empty leaf (T.leaf), 2 = walk over.
+//
+// Written without short-circuit operators and if/else ladders: every `||`, `&&` and ladder rung
+// costs an s_and_saveexec / s_cbranch pair, and the scalar unit is shared by the 20 waves of a CU —
+// the branchy form of this step was ~110 instructions, more than half of them scalar mask juggling,
+// and took ~4400 cycles per wave-step whatever the scene size (profiles/r01_f_trace_stamps.txt).
 template <bool COUNT>
 PT_D int trav_step(const DevScene& S, Trav& T, const TravStack& st, float limit, LocalCtr& lc) {
-    uint2 nd = S.kd_nodes[T.node];
+    const uint2 nd = S.kd_nodes[T.node];
     if (COUNT) lc.nodes++;
-    uint32_t axis = nd.y & 3u;
+    const uint32_t axis = nd.y & 3u;
     if (axis != 3u) {
-        float split = __uint_as_float(nd.x);
-        // The per-axis quantities are computed for all three axes and selected by VALUE: selecting
-        // the operands (axis == 0 ? o.x : ...) makes the compiler keep o/d/inv in a scratch array
-        // and index it dynamically — three dependent scratch loads on every node step.
-        float tp0 = (split - T.o.x) * T.inv.x, tp1 = (split - T.o.y) * T.inv.y, tp2 = (split - T.o.z) * T.inv.z;
-        bool bf0 = (T.o.x < split) || (T.o.x == split && T.d.x <= 0.f);
-        bool bf1 = (T.o.y < split) || (T.o.y == split && T.d.y <= 0.f);
-        bool bf2 = (T.o.z < split) || (T.o.z == split && T.d.z <= 0.f);
-        float tplane = axis == 0 ? tp0 : (axis == 1 ? tp1 : tp2);
-        bool below_first = axis == 0 ? bf0 : (axis == 1 ? bf1 : bf2);
-        uint32_t below = T.node + 1, above = nd.y >> 2;
-        uint32_t first = below_first ? below : above;
-        uint32_t second = below_first ? above : below;
-        if (tplane > T.tmax * PT_EXIT_REL + PT_EXIT_ABS || tplane <= 0.f) {
-            T.node = first;
-        } else if (tplane < T.tmin * (2.f - PT_EXIT_REL) - PT_EXIT_ABS) {
-            T.node = second;
-        } else {
+        const float split = __uint_as_float(nd.x);
+        // all three axes evaluated, result selected by value (see the note on scratch arrays above)
+        const float tp0 = (split - T.o.x) * T.inv.x, tp1 = (split - T.o.y) * T.inv.y, tp2 = (split - T.o.z) * T.inv.z;
+        const bool bf0 = (T.o.x < split) | ((T.o.x == split) & (T.d.x <= 0.f));
+        const bool bf1 = (T.o.y < split) | ((T.o.y == split) & (T.d.y <= 0.f));
+        const bool bf2 = (T.o.z < split) | ((T.o.z == split) & (T.d.z <= 0.f));
+        const bool ax0 = axis == 0u, ax1 = axis == 1u;
+        const float tplane = ax0 ? tp0 : (ax1 ? tp1 : tp2);
+        const bool below_first = ax0 ? bf0 : (ax1 ? bf1 : bf2);
+        const uint32_t pair = nd.y >> 2;  // children = pair (below), pair + 1 (above)
+        const uint32_t first = pair + (below_first ? 0u : 1u), second = pair + (below_first ? 1u : 0u);
+        const bool only_first = (tplane > T.tmax * PT_EXIT_REL + PT_EXIT_ABS) | (tplane <= 0.f);
+        const bool only_second = !only_first & (tplane < T.tmin * (2.f - PT_EXIT_REL) - PT_EXIT_ABS);
+        const bool both = !(only_first | only_second);  // also for a NaN plane parameter: conservative
+        if (both) {
             stack_push(st, T.sp, second, T.tmax);
             ++T.sp;
-            T.node = first;
             T.tmax = tplane;
         }
+        T.node = only_second ? second : first;
         return 0;
     }
     if (nd.y >> 2) {
@@ -475,6 +481,21 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
         }
     };
 
+#ifdef WF_STAMPS
+    // Diagnostic build only: shader-clock cycles of every loop phase, summed per wavefront (lane 0
+    // adds them to spare counter slots at the end).  Never enabled in the shipped library.
+    unsigned long long st_refill = 0, st_walk = 0, st_leaf = 0, st_done = 0, st_t0, st_walk_lanes = 0, st_walk_steps = 0,
+                       st_leaf_lanes = 0, st_leaf_runs = 0;
+#define WF_STAMP(acc)                                  \
+    do {                                               \
+        unsigned long long _t = __builtin_readcyclecounter(); \
+        acc += _t - st_t0;                             \
+        st_t0 = _t;                                    \
+    } while (0)
+    st_t0 = __builtin_readcyclecounter();
+#else
+#define WF_STAMP(acc) do {} while (0)
+#endif
     while (true) {
         // ---- refill
         bool need = !active && !exhausted;
@@ -507,6 +528,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
                 cast_done = !valid_item || !trav_start(S, T, o, d, 0.f);
             }
         }
+        WF_STAMP(st_refill);
         if (!__any(active)) {
             if (__all(exhausted)) break;
             continue;
@@ -515,20 +537,46 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
         for (uint32_t k = 0; k < W.walk_steps; ++k) {
             bool walking = active && !at_leaf && !cast_done;
             if (!__any(walking)) break;
+#ifdef WF_STAMPS
+            st_walk_lanes += __popcll(__ballot(walking));
+            st_walk_steps++;
+#endif
             if (walking) {
                 int r = trav_step<COUNT>(S, T, st, best.key, lc);
                 at_leaf = r == 1;
                 cast_done = r == 2;
             }
         }
+        WF_STAMP(st_walk);
         // ---- phase B: primitives of the parked leaves
+#ifdef WF_STAMPS
+        if (__any(active && at_leaf)) {
+            st_leaf_lanes += __popcll(__ballot(active && at_leaf));
+            st_leaf_runs++;
+        }
+#endif
         if (active && at_leaf) {
             leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc);
             at_leaf = false;
             cast_done = !trav_pop(T, st, best.key);
         }
+        WF_STAMP(st_leaf);
         if (active && cast_done) complete();
+        WF_STAMP(st_done);
     }
+#ifdef WF_STAMPS
+    if (COUNT && (threadIdx.x & 63u) == 0) {
+        unsigned long long* slot = &gctr->samples;  // DevCounters is an array of u64
+        atomicAdd(slot + 12, st_refill);
+        atomicAdd(slot + 13, st_walk);
+        atomicAdd(slot + 14, st_leaf);
+        atomicAdd(slot + 15, st_done);
+        atomicAdd(slot + 16, st_walk_lanes);
+        atomicAdd(slot + 17, st_walk_steps);
+        atomicAdd(slot + 18, st_leaf_lanes);
+        atomicAdd(slot + 19, st_leaf_runs);
+    }
+#endif
     if (COUNT) {
         atomicAdd(&gctr->segments, (unsigned long long)lc.segments);
         atomicAdd(&gctr->nodes_visited, (unsigned long long)lc.nodes);
