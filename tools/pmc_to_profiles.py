@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Fold the PMC passes of tools/pmc_profile.sh (full-size bench, --steps 1 --warmup 0) into
+profiles/<tag>_pmc.json and refresh profiles/latest_traffic.json (read by bench.py).
+
+    python tools/pmc_to_profiles.py gpurun_out/pmc_r01_g r01_g 500000 1920 1080 128 5 1
+"""
+import csv, glob, json, sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+workload = [int(v) for v in sys.argv[3:9]]
+acc = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(int)
+for path in sorted(glob.glob(f"{src}/pass*/**/*counter_collection.csv", recursive=True)):
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        if not any(s in k for s in ("k_wf_", "k_accumulate", "k_postprocess")):
+            continue
+        name = k.split("<")[0].split("(")[0].replace("void ", "")
+        acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
+        seen.add((name, r["Dispatch_Id"]))
+    for name, _ in seen:
+        cnt[(name, path.split("/")[-3])] += 1
+out = {}
+for name, c in acc.items():
+    n = max(v for (nm, _), v in cnt.items() if nm == name)
+    fetch_kb, write_kb = c.get("FETCH_SIZE", 0), c.get("WRITE_SIZE", 0)
+    cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8
+    out[name] = {
+        "dispatches_per_frame": n,
+        # MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128 B request on gfx950 -> doubled; WRITE_SIZE exact
+        "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024 / n,
+        "hbm_bytes_per_frame": (2 * fetch_kb + write_kb) * 1024,
+        "FETCH_SIZE_KB_total": fetch_kb, "WRITE_SIZE_KB_total": write_kb,
+        "active_lanes_per_valu_inst": round(c.get("SQ_THREAD_CYCLES_VALU", 0) / max(1, c.get("SQ_INSTS_VALU", 1)), 1),
+        "wait_pct_of_wave_cycles": round(100 * c.get("SQ_WAIT_ANY", 0) / max(1, c.get("SQ_WAVE_CYCLES", 1)), 1),
+        "l2_hit_pct": round(100 * c.get("TCC_HIT_sum", 0) / max(1, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)), 1),
+        "l1_hit_pct": round(100 * (1 - c.get("TCP_TCC_READ_REQ_sum", 0) / max(1, c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 1))), 1),
+        "valu_insts": c.get("SQ_INSTS_VALU", 0), "salu_insts": c.get("SQ_INSTS_SALU", 0),
+        "branch_insts": c.get("SQ_INSTS_BRANCH", 0), "vmem_rd_insts": c.get("SQ_INSTS_VMEM_RD", 0),
+        "valu_insts_per_cu_cycle": round(c.get("SQ_INSTS_VALU", 0) / 256 / max(1, cyc), 3),
+        "salu_insts_per_cu_cycle": round(c.get("SQ_INSTS_SALU", 0) / 256 / max(1, cyc), 3),
+        "kernel_ms_profiled": round(cyc / 2.1e6, 2),
+    }
+json.dump({"workload": workload, "kernels": out}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+t = out["k_wf_trace"]
+json.dump({"workload": workload, "kernel": "k_wf_trace", "hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
+           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_profile.sh); bytes = "
+                     "(2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per 128 B "
+                     "request); calibration in this pipeline: k_accumulate reads 12 B/sample -> FETCH_SIZE reads 0.48x, "
+                     "k_wf_generate writes 64 B/item -> WRITE_SIZE reads 0.96-1.0x",
+           "source": f"profiles/{tag}_pmc.json"}, open("profiles/latest_traffic.json", "w"), indent=1)
+for k, v in out.items():
+    print(k, {a: v[a] for a in ("dispatches_per_frame", "hbm_bytes_per_frame", "active_lanes_per_valu_inst",
+                                 "wait_pct_of_wave_cycles", "l1_hit_pct", "l2_hit_pct", "kernel_ms_profiled")})
+print("total HBM bytes per frame: %.1f GB" % (sum(v["hbm_bytes_per_frame"] for v in out.values()) / 1e9))
