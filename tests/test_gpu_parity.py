@@ -279,6 +279,40 @@ def test_translucent_generated_scene_is_bit_identical(pta, oracle):
     assert c["restarts"] > 0
 
 
+def _write_isf(tmp_path, name, models, lights, background=(0.25, 0.5, 1.0)):
+    import json
+    cam = {"transform": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 4, 1]], "fov": 0.8, "zfar": 100.0, "znear": 0.1}
+    p = tmp_path / f"{name}.isf"
+    p.write_text(json.dumps({"models": models, "camera": cam, "lights": lights, "background": list(background)}))
+    return p
+
+
+def test_edge_case_scenes(pta, oracle, tmp_path):
+    """Empty scene, a scene without lights, a single sphere the camera sits inside, a degenerate (zero-area)
+    triangle, odd image sizes down to 1x1 — all bit-identical to the oracle."""
+    tri = lambda a, b, c: [{"position": a, "normal": [0, 0, 1], "tex_coords": [0, 0]},
+                           {"position": b, "normal": [0, 0, 1], "tex_coords": [1, 0]},
+                           {"position": c, "normal": [0, 0, 1], "tex_coords": [0, 1]}]
+    mat = {"albedo": {"factor": [0.8, 0.7, 0.6]}, "roughness": {"factor": 0.4}}
+    point = {"type": "Point", "position": [1, 2, 3], "color": [40, 40, 40], "size": 0.1}
+    cases = {
+        "empty": ([], [point]),
+        "no_lights": ([{"type": "Mesh", "triangles": [tri([-1, -1, 0], [1, -1, 0], [0, 1, 0])], "material": mat}], []),
+        "inside_sphere": ([{"type": "Sphere", "radius": 10.0, "center": [0, 0, 0], "material": mat}], [point]),
+        "degenerate": ([{"type": "Mesh", "triangles": [tri([0, 0, 0], [0, 0, 0], [0, 0, 0]),
+                                                       tri([-1, -1, 0], [1, -1, 0], [0, 1, 0])], "material": mat},
+                        {"type": "Mesh", "triangles": [], "material": mat}],
+                       [point, {"type": "Directional", "direction": [0, 0, -1], "color": [1, 1, 1]}]),
+    }
+    for name, (models, lights) in cases.items():
+        scene = pta.HostScene.load_isf(_write_isf(tmp_path, name, models, lights))
+        g = pta.GpuScene(scene)
+        for (w, h, spp, b) in ((1, 1, 3, 2), (37, 23, 5, 6), (64, 8, 2, 0)):
+            prof = pta.Profile.make(w, h, spp, b)
+            ok, u8_ok, exact, same = compare_render(pta, oracle, scene, g, prof)
+            assert exact == 1.0 and same, (name, w, h)
+
+
 def test_host_buffer_errors(pta, scene_cache, gpu_scene_cache):
     g = gpu_scene_cache("cube")
     with pytest.raises(pta.PtError):
