@@ -209,6 +209,14 @@ int pt_assemble_tiles(const pt_profile* profile, uint32_t shard_count, uint32_t 
                       uint32_t tile_h, uint64_t slice_pixels, uint32_t elem_bytes,
                       const void* d_gathered, void* d_image, void* hip_stream);
 
+/* `--debug-textures` (src/renderer/debug_renderer.rs:11-105): one pixel-centre primary ray per
+ * pixel, first entry of ray_cast() only, seven RGB8 planes of width*height*3 bytes each, in this
+ * order: normal (n*0.5+0.5), albedo, opacity, metalness, roughness, emissive, ior/3 — each channel
+ * `(v * 255.) as u8`, pixels without a hit stay 0.  *any_hit = 0 means no pixel hit anything (the
+ * reference then writes no file at all).  planes is a HOST pointer. */
+enum { PT_DEBUG_PLANES = 7 };
+int pt_debug_render(const pt_scene* scene, uint32_t width, uint32_t height, uint8_t* planes, int* any_hit);
+
 /* ------------------------------------------------------------------ */
 /* measurement                                                         */
 /* ------------------------------------------------------------------ */

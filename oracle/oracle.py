@@ -28,6 +28,7 @@ def lib():
         L.pto_scene_destroy.restype = None
         L.pto_render.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp, vp]
         L.pto_post_process.argtypes = [vp, vp, C.c_uint64, vp]
+        L.pto_debug_render.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_int)]
         L.pto_trace_rays_all.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
         L.pto_intersect_triangles.argtypes = [vp, vp, C.c_uint64, vp]
         L.pto_rng_words.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
@@ -72,6 +73,13 @@ class OracleScene:
         _check(lib().pto_render(self.handle, C.byref(profile), pixel_begin, end, threads, rgb.ctypes.data,
                                 acc.ctypes.data, C.byref(stats)))
         return rgb, acc, dict(zip(STAT_NAMES, (int(v) for v in stats)))
+
+    def debug_render(self, width, height):
+        planes = np.zeros((7, width * height, 3), np.uint8)
+        any_hit = C.c_int(0)
+        _check(lib().pto_debug_render(self.handle, width, height, planes.ctypes.data, C.byref(any_hit)))
+        names = ("normal", "albedo", "opacity", "metalness", "roughness", "emissive", "ior")
+        return dict(zip(names, planes)) if any_hit.value else {}
 
     def trace_all(self, rays, max_hits=8):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

@@ -947,6 +947,47 @@ int pto_render(const pto_scene* s, const pt_profile* profile, uint64_t pixel_beg
     return PT_OK;
 }
 
+// debug_render / render_debug_pixels — renderer/debug_renderer.rs:11-105 (unpinned by the reference's tests)
+int pto_debug_render(const pto_scene* s, uint32_t width, uint32_t height, uint8_t* planes, int* any_hit) {
+    if (!s || !planes || !any_hit) return set_err(PT_ERR_INVALID, "pto_debug_render: null argument");
+    size_t npix = (size_t)width * height;
+    memset(planes, 0, npix * 3 * 7);
+    *any_hit = 0;
+    CastScratch sc;
+    uint64_t errs = 0;
+    float width_f = (float)width, height_f = (float)height, image_ratio = width_f / height_f, fov = s->d.camera.fov;
+    const float* M = s->d.camera.transform;
+    V3 c0 = v3(M[0], M[1], M[2]), c1 = v3(M[4], M[5], M[6]), c2 = v3(M[8], M[9], M[10]), c3 = v3(M[12], M[13], M[14]);
+    for (uint32_t x = 0; x < width; ++x)
+        for (uint32_t y = 0; y < height; ++y) {
+            float screen_x = (float)x + 0.5f;
+            screen_x = screen_x / width_f * 2.f - 1.f;
+            screen_x *= tanf(fov / 2.f) * image_ratio;
+            float screen_y = (float)y + 0.5f;
+            screen_y = 1.f - screen_y / height_f * 2.f;
+            screen_y *= tanf(fov / 2.f);
+            V3 dir = normalize(v3(screen_x, screen_y, -1.f));
+            Ray ray{c3, c0 * dir.x + c1 * dir.y + c2 * dir.z + c3 * 0.0f};
+            ray_cast(*s, ray, sc, &errs);
+            if (sc.hits.empty()) continue;
+            const Hit& hit = sc.hits[0];
+            MaterialSample m = get_material_sample(*s, hit, hit.model);
+            V3 normal = get_normal(*s, hit, hit.model);
+            V3 one = v3(1.f, 1.f, 1.f);
+            V3 v[7] = {v3(normal.x * 0.5f + 0.5f, normal.y * 0.5f + 0.5f, normal.z * 0.5f + 0.5f), m.albedo, one * m.opacity,
+                       one * m.metalness, one * m.roughness, m.emissive, one * m.ior / 3.f};
+            size_t i = (size_t)y * width + x;
+            for (int p = 0; p < 7; ++p) {
+                uint8_t* out = planes + ((size_t)p * npix + i) * 3;
+                out[0] = as_u8(v[p].x * 255.f);
+                out[1] = as_u8(v[p].y * 255.f);
+                out[2] = as_u8(v[p].z * 255.f);
+            }
+            *any_hit = 1;
+        }
+    return PT_OK;
+}
+
 int pto_post_process(const pt_profile* profile, const float* accum, uint64_t n, uint8_t* rgb8) {
     if (!profile || !accum || !rgb8) return set_err(PT_ERR_INVALID, "pto_post_process: null argument");
     for (uint64_t i = 0; i < n; ++i)

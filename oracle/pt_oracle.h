@@ -49,6 +49,9 @@ typedef struct pto_stats {
 int pto_render(const pto_scene* s, const pt_profile* profile, uint64_t pixel_begin,
                uint64_t pixel_end, int threads, uint8_t* rgb8, float* accum, pto_stats* stats);
 
+/* debug_render (renderer/debug_renderer.rs): 7 RGB8 planes, see pt_debug_render in ptgpu.h. */
+int pto_debug_render(const pto_scene* s, uint32_t width, uint32_t height, uint8_t* planes, int* any_hit);
+
 /* Renderer::post_processing on n accumulated pixels (accum = sum over samples). */
 int pto_post_process(const pt_profile* profile, const float* accum, uint64_t n, uint8_t* rgb8);
 

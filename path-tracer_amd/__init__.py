@@ -21,6 +21,7 @@ PT_LIGHT_POINT, PT_LIGHT_DIRECTIONAL = 0, 1
 PT_TONEMAP_REINHARD, PT_TONEMAP_FILMIC, PT_TONEMAP_ACES = 0, 1, 2
 PT_FLAG_TIMING, PT_FLAG_COUNTERS = 1, 2
 TONEMAPS = {"REINHARD": 0, "FILMIC": 1, "ACES": 2}
+DEBUG_PLANES = ("normal", "albedo", "opacity", "metalness", "roughness", "emissive", "ior")
 
 
 class Texture(C.Structure):
@@ -149,7 +150,7 @@ HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_s
                 "pth_kd_free", "pth_last_error"]
 # Every symbol include/ptgpu.h declares.
 GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_local_pixel_count", "pt_local_pixel_map",
-               "pt_render", "pt_render_device", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
+               "pt_render", "pt_render_device", "pt_debug_render", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
                "pt_scene_get_info", "pt_trace_rays", "pt_trace_rays_all", "pt_intersect_triangles",
                "pt_rng_words", "pt_eval_math", "pt_last_error", "pt_version"]
 
@@ -208,6 +209,7 @@ def gpu_lib():
         L.pt_render_device.argtypes = [vp, C.POINTER(Profile), C.POINTER(Opts), vp, vp, vp]
         L.pt_assemble_tiles.argtypes = [C.POINTER(Profile), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                         C.c_uint32, vp, vp, vp]
+        L.pt_debug_render.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_int)]
         L.pt_get_timing.argtypes = [vp, C.POINTER(Timing)]
         L.pt_get_counters.argtypes = [vp, C.POINTER(Counters)]
         L.pt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
@@ -309,6 +311,16 @@ class GpuScene:
 
     def render_device(self, profile, opts, d_rgb8, d_accum, stream=0):
         check_gpu(self.lib.pt_render_device(self.handle, C.byref(profile), C.byref(opts), d_rgb8, d_accum, stream))
+
+    def debug_render(self, width, height):
+        """--debug-textures planes: dict name -> [H*W, 3] uint8, or {} when nothing was hit."""
+        import numpy as np
+        planes = np.zeros((7, width * height, 3), np.uint8)
+        any_hit = C.c_int(0)
+        check_gpu(self.lib.pt_debug_render(self.handle, width, height, planes.ctypes.data, C.byref(any_hit)))
+        if not any_hit.value:
+            return {}
+        return dict(zip(DEBUG_PLANES, planes))
 
     def timing(self):
         t = Timing()

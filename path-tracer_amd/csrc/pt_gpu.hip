@@ -355,6 +355,37 @@ __global__ __launch_bounds__(256) void k_trace_all(DevScene S, const float* __re
     for (uint32_t j = cnt; j < max_hits; ++j) out[i * max_hits + j] = pt_hit{-1, 0, 0.f, 0.f, 0.f};
 }
 
+// render_debug_pixels (src/renderer/debug_renderer.rs:64-105): first hit of the pixel-centre ray
+__global__ __launch_bounds__(256) void k_debug(DevScene S, uint32_t width, uint32_t height, uint8_t* __restrict__ planes,
+                                               int* __restrict__ any_hit) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= width * height) return;
+    uint32_t x = i % width, y = i / width;
+    f3 o, d;
+    primary_ray(S, x, y, width, height, 0.5f, 0.5f, o, d);  // screen = x + 0.5 (debug_renderer.rs:24-30)
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};
+    RawHit h;
+    if (!next_hit<false>(S, o, d, -INFINITY, 0u, h, lc)) return;
+    Surface sf;
+    make_surface(S, o, d, h, sf);
+    MatSample ms;
+    material_sample(S, sf.model, sf.sphere, sf.uv, ms);
+    f3 n = shading_normal(S, sf);
+    float ior = S.materials[sf.model].ior;
+    const f3 one = mk3(1.f, 1.f, 1.f);
+    f3 v[PT_DEBUG_PLANES] = {mk3(n.x * 0.5f + 0.5f, n.y * 0.5f + 0.5f, n.z * 0.5f + 0.5f), ms.albedo, one * ms.opacity,
+                             one * ms.metalness, one * ms.roughness, ms.emissive, (one * ior) / 3.f};
+    size_t npix = (size_t)width * height;
+#pragma unroll
+    for (int p = 0; p < PT_DEBUG_PLANES; ++p) {
+        uint8_t* out = planes + ((size_t)p * npix + i) * 3;
+        out[0] = as_u8(v[p].x * 255.f);
+        out[1] = as_u8(v[p].y * 255.f);
+        out[2] = as_u8(v[p].z * 255.f);
+    }
+    *any_hit = 1;
+}
+
 __global__ __launch_bounds__(256) void k_isect(const float* __restrict__ rays, const float* __restrict__ tris,
                                                uint64_t n, pt_hit* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -1056,6 +1087,25 @@ int pt_render(const pt_scene* scene, const pt_profile* profile, const pt_opts* o
         HIP_CHECK(hipDeviceSynchronize());
         if (rgb8) d_rgb.fetch(rgb8, n * 3);
         if (accum) d_acc.fetch(accum, n * 3);
+    });
+}
+
+int pt_debug_render(const pt_scene* scene, uint32_t width, uint32_t height, uint8_t* planes, int* any_hit) {
+    return guarded([&] {
+        if (!scene || !planes || !any_hit) fail(PT_ERR_INVALID, "pt_debug_render: null argument");
+        if (!width || !height || (uint64_t)width * height >= (1ull << 31)) fail(PT_ERR_INVALID, "pt_debug_render: bad resolution");
+        HIP_CHECK(hipSetDevice(scene->device));
+        size_t bytes = (size_t)width * height * 3 * PT_DEBUG_PLANES;
+        Staged<uint8_t> d_planes(nullptr, bytes);
+        Staged<int> d_flag(nullptr, 1);
+        HIP_CHECK(hipMemset(d_planes.d, 0, bytes));
+        HIP_CHECK(hipMemset(d_flag.d, 0, sizeof(int)));
+        hipLaunchKernelGGL(k_debug, dim3((width * height + 255u) / 256u), dim3(256), 0, 0, scene->dev, width, height,
+                           d_planes.d, d_flag.d);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        d_planes.fetch(planes, bytes);
+        d_flag.fetch(any_hit, 1);
     });
 }
 

@@ -36,7 +36,7 @@ void usage_render(FILE* f) {
           "  -o, --output <OUTPUT>    Output image name [env: OUTPUT=] [default: render.png]\n"
           "  -q, --quiet              No progress bar printed\n"
           "  -v, --viewer             Display a viewer (accepted, ignored on the GPU path)\n"
-          "      --debug-textures     Generate debug textures (not implemented on the GPU path)\n"
+          "      --debug-textures     Generate debug textures\n"
           "  -p, --profile <PROFILE>  A path to the yaml file containing all the rendering profile information [env: PROFILE=]\n"
           "      --device <N>         HIP device ordinal [default: 0]\n"
           "      --stats              Print timing statistics as JSON on stderr\n"
@@ -123,7 +123,6 @@ int run_render(int argc, char** argv) {
             have_profile = true;
         }
     }
-    if (debug_textures) die("--debug-textures is not implemented on the GPU path (SURVEY §8-f2)");
 
     // Profile::load / Default (main.rs:33-36)
     pt_profile profile;
@@ -137,6 +136,22 @@ int run_render(int argc, char** argv) {
     pt_scene* scene = nullptr;
     if (pt_scene_create(pth_scene_desc(hscene), device, &scene) != PT_OK) die(pt_last_error());
     auto t2 = std::chrono::steady_clock::now();
+
+    if (debug_textures) {  // debug_render(&scene, profile.resolution); return (main.rs:40-43)
+        static const char* names[PT_DEBUG_PLANES] = {"normal", "albedo", "opacity", "metalness", "roughness", "emissive", "ior"};
+        size_t plane = (size_t)profile.width * profile.height * 3;
+        std::vector<uint8_t> planes(plane * PT_DEBUG_PLANES);
+        int any_hit = 0;
+        if (pt_debug_render(scene, profile.width, profile.height, planes.data(), &any_hit) != PT_OK) die(pt_last_error());
+        if (any_hit)  // the reference creates the buffers on the first hit: no hit, no files
+            for (int p = 0; p < PT_DEBUG_PLANES; ++p)
+                if (pth_png_write_rgb8((std::string(names[p]) + ".png").c_str(), profile.width, profile.height,
+                                       planes.data() + plane * p) != PT_OK)
+                    die(pth_last_error());
+        pt_scene_destroy(scene);
+        pth_scene_free(hscene);
+        return 0;
+    }
 
     // Renderer::new + render (main.rs:46-47)
     Progress prog{quiet, std::chrono::steady_clock::now()};

@@ -39,6 +39,21 @@ def test_cli_bad_profile_and_env(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_debug_textures(tmp_path, pta, gpu_scene_cache):
+    import numpy as np
+    from PIL import Image
+    prof = tmp_path / "p.yml"
+    prof.write_text("resolution:\n  width: 80\n  height: 60\n")
+    r = subprocess.run([str(EXE), "render", str(SCENES / "spheres" / "scene.isf"), "--debug-textures", "-p", str(prof)],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    planes = gpu_scene_cache("spheres").debug_render(80, 60)
+    for name in pta.DEBUG_PLANES:
+        assert np.array_equal(np.asarray(Image.open(tmp_path / f"{name}.png")).reshape(-1, 3), planes[name]), name
+    assert not (tmp_path / "render.png").exists()
+
+
+@pytest.mark.gpu
 def test_cli_renders_like_the_library(tmp_path, pta, gpu_scene_cache):
     import numpy as np
     from PIL import Image

@@ -313,6 +313,23 @@ def test_edge_case_scenes(pta, oracle, tmp_path):
             assert exact == 1.0 and same, (name, w, h)
 
 
+@pytest.mark.parametrize("name", ["head", "spheres", "alpha_transparency", "cube"])
+def test_debug_textures_match_oracle(pta, oracle, scene_cache, gpu_scene_cache, name):
+    """--debug-textures (renderer/debug_renderer.rs): seven G-buffer planes, GPU == oracle."""
+    got = gpu_scene_cache(name).debug_render(160, 120)
+    ref = oracle.OracleScene(scene_cache(name).desc, oracle.PTO_BVH).debug_render(160, 120)
+    assert sorted(got) == sorted(ref) == sorted(pta.DEBUG_PLANES)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+    assert got["normal"].any() and got["albedo"].any()
+
+
+def test_debug_textures_without_hits_write_nothing(pta, oracle, tmp_path):
+    scene = pta.HostScene.load_isf(_write_isf(tmp_path, "empty_dbg", [], []))
+    assert pta.GpuScene(scene).debug_render(32, 16) == {}
+    assert oracle.OracleScene(scene.desc, oracle.PTO_BVH).debug_render(32, 16) == {}
+
+
 def test_host_buffer_errors(pta, scene_cache, gpu_scene_cache):
     g = gpu_scene_cache("cube")
     with pytest.raises(pta.PtError):
