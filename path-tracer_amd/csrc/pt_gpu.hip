@@ -824,8 +824,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         cap = (uint32_t)std::min<uint64_t>(items_per_batch, std::max<uint32_t>(64u, wf_cap & ~63u));
         if (s.trace_blocks == 0) {
             int a = 0, b = 0, c = 0, d = 0;
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_wf_trace<false, false>, 256, 0));
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_wf_trace<true, false>, 256, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_wf_trace<false, false, false>, 256, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_wf_trace<true, false, false>, 256, 0));
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_wf_shadow<false, false>, 256, 0));
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, k_wf_shadow<true, false>, 256, 0));
             s.trace_blocks = std::max(1, alpha ? b : a) * s.n_cu;
@@ -905,15 +905,30 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 W.walk_steps = std::max(1u, wf_walk);
                 WfCounters* wctr = (WfCounters*)s.wf_ctr.p;
                 HIP_CHECK(hipMemsetAsync(wctr, 0, sizeof(WfCounters) * (p.bounces + 3), stream));
-                stage_begin(0);
-                hipLaunchKernelGGL(k_wf_generate, dim3((W.n_items + 255u) / 256u), dim3(256), 0, stream, s.dev, W, d_tiles,
-                                   (float4*)s.wf_queue[0].p, wctr, gctr);
-                HIP_CHECK(hipGetLastError());
-                stage_end();
+                // bounce 0 of opaque scenes derives the camera rays in place (no generate kernel, no queue[0])
+                const bool fused_primary = !alpha;
+                if (!fused_primary) {
+                    stage_begin(0);
+                    hipLaunchKernelGGL(k_wf_generate, dim3((W.n_items + 255u) / 256u), dim3(256), 0, stream, s.dev, W, d_tiles,
+                                       (float4*)s.wf_queue[0].p, wctr, gctr);
+                    HIP_CHECK(hipGetLastError());
+                    stage_end();
+                }
                 for (uint32_t b = 0; b <= p.bounces; ++b) {
                     W.bounce = b;
                     float4* q_in = (float4*)s.wf_queue[b & 1].p;
                     float4* q_out = (float4*)s.wf_queue[(b + 1) & 1].p;
+                    const bool prim = fused_primary && b == 0;
+#define PT_LAUNCH_ACP(kernel, grid, threads, ...)                                                                                     \
+    do {                                                                                                                              \
+        if (prim && counting) hipLaunchKernelGGL((kernel<false, true, true>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__);     \
+        else if (prim) hipLaunchKernelGGL((kernel<false, false, true>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__);           \
+        else if (alpha && counting) hipLaunchKernelGGL((kernel<true, true, false>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__); \
+        else if (alpha) hipLaunchKernelGGL((kernel<true, false, false>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__);          \
+        else if (counting) hipLaunchKernelGGL((kernel<false, true, false>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((kernel<false, false, false>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__);                    \
+        HIP_CHECK(hipGetLastError());                                                                                                 \
+    } while (0)
 #define PT_LAUNCH_AC(kernel, grid, ...)                                                                         \
     do {                                                                                                        \
         if (alpha && counting) hipLaunchKernelGGL((kernel<true, true>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);    \
@@ -922,30 +937,21 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         else hipLaunchKernelGGL((kernel<false, false>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                    \
         HIP_CHECK(hipGetLastError());                                                                           \
     } while (0)
-#define PT_LAUNCH_SHADE(kernel, grid, ...)                                                                      \
-    do {                                                                                                        \
-        if (alpha && counting) hipLaunchKernelGGL((kernel<true, true>), dim3(grid), dim3(WF_SHADE_THREADS), 0, stream, __VA_ARGS__); \
-        else if (alpha) hipLaunchKernelGGL((kernel<true, false>), dim3(grid), dim3(WF_SHADE_THREADS), 0, stream, __VA_ARGS__);       \
-        else if (counting) hipLaunchKernelGGL((kernel<false, true>), dim3(grid), dim3(WF_SHADE_THREADS), 0, stream, __VA_ARGS__);    \
-        else hipLaunchKernelGGL((kernel<false, false>), dim3(grid), dim3(WF_SHADE_THREADS), 0, stream, __VA_ARGS__);                 \
-        HIP_CHECK(hipGetLastError());                                                                           \
-    } while (0)
                     stage_begin(1);
-                    PT_LAUNCH_AC(k_wf_trace, s.trace_blocks, s.dev, W, q_in, (uint4*)s.wf_hits.p, wctr, gctr);
+                    PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, 256, s.dev, W, d_tiles, q_in, (uint4*)s.wf_hits.p, wctr, gctr);
                     stage_end();
                     ++launches;
                     stage_begin(2);
-                    // PT_LAUNCH_AC launches 256-thread workgroups; the shade kernel wants WF_SHADE_THREADS
-                    PT_LAUNCH_SHADE(k_wf_shade, (uint32_t)(s.n_cu * 4), s.dev, W, (const float4*)q_in,
-                                 (const uint4*)s.wf_hits.p, q_out, (float4*)s.wf_shadow.p, (float4*)s.wf_contrib.p,
-                                 (float*)s.staging_buf.p, wctr, gctr);
+                    PT_LAUNCH_ACP(k_wf_shade, (uint32_t)(s.n_cu * 4), WF_SHADE_THREADS, s.dev, W, d_tiles, (const float4*)q_in,
+                                  (const uint4*)s.wf_hits.p, q_out, (float4*)s.wf_shadow.p, (float4*)s.wf_contrib.p,
+                                  (float*)s.staging_buf.p, wctr, gctr);
                     stage_end();
                     stage_begin(3);
                     PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, s.dev, W, (const float4*)s.wf_shadow.p,
                                  (const float4*)s.wf_contrib.p, q_out, (float*)s.staging_buf.p, wctr, gctr);
                     stage_end();
+#undef PT_LAUNCH_ACP
 #undef PT_LAUNCH_AC
-#undef PT_LAUNCH_SHADE
                 }
             }
         }

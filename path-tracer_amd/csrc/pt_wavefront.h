@@ -376,6 +376,14 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevScene S, WfParams W, con
                        __uint_as_float((uint32_t)(seed >> 32)));
 }
 
+// Camera ray of a work item from its first two RNG words (mod.rs:107-124).
+PT_D void item_primary_ray(const DevScene& S, const RenderParams& P, const ItemRef& it, uint32_t w0, uint32_t w1, f3& o,
+                           f3& d) {
+    float r1 = (float)(w0 >> 8) * (1.0f / 16777216.0f);
+    float r2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
+    primary_ray(S, it.x, it.y, P.width, P.height, r1, r2, o, d);
+}
+
 // Sequential draws of one path inside one kernel invocation: rng.gen::<f32>() number idx, idx + 1, ...
 // The ChaCha block holding idx is derived from the seed on first use and kept in registers.
 struct WfRng {
@@ -408,12 +416,16 @@ PT_D float wf_rng_draw(WfRng& r, uint32_t idx) {
 //            non-empty leaf parks
 //   phase B  the parked lanes run Möller–Trumbore over their leaves together, then pop
 // ---------------------------------------------------------------------------
-template <bool ALPHA, bool COUNT>
+// PRIMARY (bounce 0 of opaque scenes): there is no queue — entry i IS work item i of the chunk and the
+// camera ray is derived in place (decode + ChaCha block 0), which removes k_wf_generate's 64 B/item
+// write and this kernel's 48 B/item read.
+template <bool ALPHA, bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W,
+                                                         const uint32_t* __restrict__ tile_offsets,
                                                          float4* __restrict__ queue, uint4* __restrict__ hits,
                                                          WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     __shared__ uint2 lds_stack[WF_LDS_STACK * WF_THREADS];
-    const uint32_t n = ctr[W.bounce].queue_count;
+    const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
     uint32_t* cursor = &ctr[W.bounce].trace_work;
     uint32_t ov_node[PT_KD_STACK - WF_LDS_STACK];
     float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
@@ -505,14 +517,28 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
             uint32_t w = wave_fetch(wf, cursor, n, need, got, exhausted);
             if (got) {
                 idx = w;
-                const float4* q = queue + (size_t)idx * 4;
-                float4 q0 = q[0], q1 = q[1], q3 = q[3];
-                f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
-                const bool valid_item = __float_as_uint(q3.z) != 0xffffffffu;
-                if (ALPHA) {
-                    seed_lo = __float_as_uint(q3.x);
-                    draw = __float_as_uint(q3.y) & 0xffffu;
-                    seed_hi = __float_as_uint(q3.w);
+                f3 o, d;
+                bool valid_item;
+                if (PRIMARY) {
+                    ItemRef it = decode_item(W.P, tile_offsets, W.item_base + idx);
+                    valid_item = it.valid;
+                    o = d = mk3(0.f, 0.f, 0.f);
+                    if (valid_item) {
+                        uint32_t blk[16];
+                        pt_chacha12_block((uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples, 0u, blk);
+                        item_primary_ray(S, W.P, it, blk[0], blk[1], o, d);
+                    }
+                } else {
+                    const float4* q = queue + (size_t)idx * 4;
+                    float4 q0 = q[0], q1 = q[1], q3 = q[3];
+                    o = mk3(q0.x, q0.y, q0.z);
+                    d = mk3(q0.w, q1.x, q1.y);
+                    valid_item = __float_as_uint(q3.z) != 0xffffffffu;
+                    if (ALPHA) {
+                        seed_lo = __float_as_uint(q3.x);
+                        draw = __float_as_uint(q3.y) & 0xffffu;
+                        seed_hi = __float_as_uint(q3.w);
+                    }
                 }
                 if (COUNT && valid_item) lc.segments++;
                 if (COUNT) cast_nodes0 = lc.nodes;
@@ -592,15 +618,18 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
 // ---------------------------------------------------------------------------
 // shade: compute_radiance without the light visibility (mod.rs:230-278)
 // ---------------------------------------------------------------------------
-#define WF_SHADE_THREADS 512
-template <bool ALPHA, bool COUNT>
+#ifndef WF_SHADE_THREADS
+#define WF_SHADE_THREADS 1024  // 16 waves: one compaction atomic per 1024 entries; 128 VGPRs (512: 166, 256: 214)
+#endif
+template <bool ALPHA, bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfParams W,
+                                                  const uint32_t* __restrict__ tile_offsets,
                                                   const float4* __restrict__ queue_in, const uint4* __restrict__ hits,
                                                   float4* __restrict__ queue_out, float4* __restrict__ shadow_q,
                                                   float4* __restrict__ contrib, float* __restrict__ staging,
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
-    const uint32_t n = ctr[W.bounce].queue_count;
-    uint32_t n_draws = 0;
+    const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
+    uint32_t n_draws = 0, n_new = 0;
     __shared__ uint32_t sh_cnt[2][WF_SHADE_THREADS / 64];
     __shared__ uint32_t sh_base[2];
     const uint32_t wave = threadIdx.x >> 6;
@@ -613,7 +642,29 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
     uint32_t seed_lo = 0, seed_hi = 0, draw = 0, out_slot = 0;
     RawHit h;
     bool hit = false;
-    if (live) {
+    WfRng rng;
+    rng.block = 0xffffffffu;
+    if (PRIMARY && live) {  // entry i is work item i: rebuild the path state of k_wf_generate in place
+        ItemRef it = decode_item(W.P, tile_offsets, W.item_base + i);
+        if (!it.valid) {
+            live = false;
+        } else {
+            uint64_t seed = (uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples;
+            wf_rng_init(rng, (uint32_t)seed, (uint32_t)(seed >> 32));
+            seed_lo = (uint32_t)seed;
+            seed_hi = (uint32_t)(seed >> 32);
+            rng.block = 0;
+            pt_chacha12_block(seed, 0u, rng.w);
+            item_primary_ray(S, W.P, it, rng.w[0], rng.w[1], o, d);
+            thr = mk3(1.f, 1.f, 1.f);
+            color = mk3(0.f, 0.f, 0.f);
+            draw = 2;
+            out_slot = (it.sample - 1u - W.P.sample_begin) * W.P.n_local + it.out_index;
+            hit = unpack_hit(hits[i], h);
+            if (COUNT) n_new++;
+        }
+    }
+    if (!PRIMARY && live) {
         const float4* q = queue_in + (size_t)i * 4;
         float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         o = mk3(q0.x, q0.y, q0.z);
@@ -651,8 +702,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         color = color + mul_ew(thr, ms.emissive);
         to_shadow = true;
         bool ended = false;
-        WfRng rng;
-        wf_rng_init(rng, seed_lo, seed_hi);
+        if (!PRIMARY) wf_rng_init(rng, seed_lo, seed_hi);
         if (bounce < bounces) {
             next_o = surf.pos + surf.normal * 0.00001f;
             float r1 = wf_rng_draw(rng, draw++);
@@ -713,9 +763,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
             contrib[(size_t)li * W.cap + sh_idx] = make_float4(c.x, c.y, c.z, 0.f);
         }
     }
-    if (COUNT && live) n_draws += draw - (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu);
+    if (COUNT && live) n_draws += PRIMARY ? draw : draw - (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu);
     }  // grid-stride loop
     if (COUNT && n_draws) atomicAdd(&gctr->rng_draws, (unsigned long long)n_draws);
+    if (COUNT && n_new) atomicAdd(&gctr->samples, (unsigned long long)n_new);
 }
 
 // ---------------------------------------------------------------------------
