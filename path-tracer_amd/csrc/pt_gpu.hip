@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -1131,24 +1132,45 @@ int pt_assemble_tiles(const pt_profile* profile, uint32_t shard_count, uint32_t 
                                      hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
             return;
         }
-        uint32_t max_local = 0;
-        std::vector<TileMap> maps;
-        for (uint32_t r = 0; r < on.shard_count; ++r) {
-            maps.push_back(make_tile_map(*profile, on, r));
-            max_local = std::max(max_local, maps.back().n_local_tiles);
-            if (maps.back().n_local > slice_pixels) fail(PT_ERR_INVALID, "slice_pixels too small for rank %u", r);
+        // rank/tile offset table: built once per (resolution, shard count, tile size, device) and kept on the
+        // device, so the per-frame call is a single kernel launch with no allocation and no host sync
+        struct Cached {
+            uint32_t* d = nullptr;
+            uint32_t max_local = 0, tiles_x = 0;
+        };
+        static std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int>, Cached> cache;
+        static std::mutex cache_mutex;
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        Cached c;
+        {
+            std::lock_guard<std::mutex> lock(cache_mutex);
+            auto key = std::make_tuple(profile->width, profile->height, on.shard_count, on.tile_w, on.tile_h, dev);
+            auto it = cache.find(key);
+            if (it == cache.end()) {
+                std::vector<TileMap> maps;
+                for (uint32_t r = 0; r < on.shard_count; ++r) {
+                    maps.push_back(make_tile_map(*profile, on, r));
+                    c.max_local = std::max(c.max_local, maps.back().n_local_tiles);
+                }
+                c.tiles_x = maps[0].tiles_x;
+                std::vector<uint32_t> table((size_t)on.shard_count * std::max(1u, c.max_local), 0);
+                for (uint32_t r = 0; r < on.shard_count; ++r)
+                    for (uint32_t lt = 0; lt < maps[r].n_local_tiles; ++lt)
+                        table[(size_t)r * c.max_local + lt] = maps[r].offsets[lt];
+                HIP_CHECK(hipMalloc((void**)&c.d, table.size() * 4));
+                HIP_CHECK(hipMemcpy(c.d, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+                it = cache.emplace(key, c).first;
+            }
+            c = it->second;
         }
-        std::vector<uint32_t> table((size_t)on.shard_count * std::max(1u, max_local), 0);
         for (uint32_t r = 0; r < on.shard_count; ++r)
-            for (uint32_t lt = 0; lt < maps[r].n_local_tiles; ++lt) table[(size_t)r * max_local + lt] = maps[r].offsets[lt];
-        Staged<uint32_t> d_table(table.data(), table.size());
+            if (make_tile_map(*profile, on, r).n_local > slice_pixels) fail(PT_ERR_INVALID, "slice_pixels too small for rank %u", r);
         uint32_t npix = profile->width * profile->height;
         hipLaunchKernelGGL(k_assemble, dim3((npix + 255u) / 256u), dim3(256), 0, (hipStream_t)hip_stream,
-                           (const uint8_t*)d_gathered, (uint8_t*)d_image, d_table.d, max_local, profile->width,
-                           profile->height, on.shard_count, on.tile_w, on.tile_h, maps[0].tiles_x, slice_pixels,
-                           elem_bytes);
+                           (const uint8_t*)d_gathered, (uint8_t*)d_image, c.d, c.max_local, profile->width,
+                           profile->height, on.shard_count, on.tile_w, on.tile_h, c.tiles_x, slice_pixels, elem_bytes);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize((hipStream_t)hip_stream));  // d_table is freed on return
     });
 }
 

@@ -4,7 +4,9 @@
 // other inside one fused kernel (measured: 8 of 64 lanes active per VALU instruction there).
 //
 //   per chunk of work items (one item = one path sample, pt_gpu.hip decode_item):
-//     k_wf_generate                 ChaCha12 block (words 0,1) + camera ray -> queue[0]
+//     k_wf_generate                 ChaCha12 block (words 0,1) + camera ray -> queue[0]   (translucent scenes
+//                                   only: opaque scenes derive the camera ray inside the bounce-0 trace and
+//                                   shade kernels, template parameter PRIMARY)
 //     for bounce = 0 .. bounces:
 //        k_wf_trace   (persistent)  ray_cast + alpha walk                   -> hit[i]
 //        k_wf_shade                 material, BRDF, next ray, termination   -> queue[b+1], shadow queue
