@@ -168,6 +168,12 @@ typedef struct pt_opts {
     uint32_t _pad;
     void (*progress)(uint32_t done_samples, uint32_t total_samples, void* user);
     void* progress_user;
+    /* Progressive output (the reference's viewer feed, renderer/mod.rs:133-141: every pixel is sent as
+     * post_processing(pixel / current_sample)).  When set, pt_render() calls it after every sample batch
+     * with the packed RGB8 image of the samples done so far (same layout as the rgb8 result, valid only
+     * during the call).  Host-buffer entry point only. */
+    void (*preview)(const uint8_t* rgb8, uint64_t n_pixels, uint32_t done_samples, uint32_t total_samples, void* user);
+    void* preview_user;
 } pt_opts;
 
 typedef struct pt_scene pt_scene;

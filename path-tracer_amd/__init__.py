@@ -68,18 +68,23 @@ class Profile(C.Structure):
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_uint32, C.c_uint32, C.c_void_p)
+PREVIEW_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p)
 
 
 class Opts(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("device", C.c_int32), ("shard_rank", C.c_uint32),
                 ("shard_count", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
                 ("sample_batch", C.c_uint32), ("_pad", C.c_uint32), ("progress", PROGRESS_FN),
-                ("progress_user", C.c_void_p)]
+                ("progress_user", C.c_void_p), ("preview", PREVIEW_FN), ("preview_user", C.c_void_p)]
 
     @classmethod
-    def make(cls, flags=0, device=-1, shard_rank=0, shard_count=1, tile_w=0, tile_h=0, sample_batch=0):
-        return cls(flags, device, shard_rank, shard_count, tile_w, tile_h, sample_batch, 0,
-                   C.cast(None, PROGRESS_FN), None)
+    def make(cls, flags=0, device=-1, shard_rank=0, shard_count=1, tile_w=0, tile_h=0, sample_batch=0, preview=None):
+        o = cls(flags, device, shard_rank, shard_count, tile_w, tile_h, sample_batch, 0,
+                C.cast(None, PROGRESS_FN), None, C.cast(None, PREVIEW_FN), None)
+        if preview is not None:
+            o._keep = PREVIEW_FN(preview)  # keep the trampoline alive with the struct
+            o.preview = o._keep
+        return o
 
 
 class Hit(C.Structure):

@@ -726,7 +726,7 @@ hipEvent_t get_event(const pt_scene& s, size_t i) {
 }
 
 void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_in, void* d_rgb8, void* d_accum,
-                   hipStream_t stream) {
+                   hipStream_t stream, bool allow_preview = false) {
     pt_opts o;
     normalise_opts(p, opts_in, o);
     if (p.samples == 0) fail(PT_ERR_INVALID, "profile.samples must be > 0");
@@ -963,6 +963,16 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             HIP_CHECK(hipGetLastError());
             stage_end();
         }
+        if (allow_preview && o.preview && d_rgb8) {
+            // viewer feed (mod.rs:133-141): post_processing(pixel / current_sample) of the samples so far
+            hipLaunchKernelGGL(k_postprocess, dim3(((uint32_t)tm.n_local + 255u) / 256u), dim3(256), 0, stream, accum,
+                               (uint8_t*)d_rgb8, (uint32_t)tm.n_local, P.sample_end, p.tonemap);
+            HIP_CHECK(hipGetLastError());
+            std::vector<uint8_t> host(tm.n_local * 3);
+            HIP_CHECK(hipMemcpyAsync(host.data(), d_rgb8, host.size(), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            o.preview(host.data(), tm.n_local, P.sample_end, p.samples, o.preview_user);
+        }
         if (o.progress) {
             HIP_CHECK(hipStreamSynchronize(stream));
             o.progress(P.sample_end, p.samples, o.progress_user);
@@ -1090,7 +1100,7 @@ int pt_render(const pt_scene* scene, const pt_profile* profile, const pt_opts* o
         uint64_t n = make_tile_map(*profile, o, o.shard_rank).n_local;
         Staged<uint8_t> d_rgb(nullptr, n * 3);
         Staged<float> d_acc(nullptr, n * 3);
-        render_device(*scene, *profile, opts, d_rgb.d, d_acc.d, nullptr);
+        render_device(*scene, *profile, opts, d_rgb.d, d_acc.d, nullptr, true);
         HIP_CHECK(hipDeviceSynchronize());
         if (rgb8) d_rgb.fetch(rgb8, n * 3);
         if (accum) d_acc.fetch(accum, n * 3);

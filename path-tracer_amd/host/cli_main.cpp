@@ -35,7 +35,7 @@ void usage_render(FILE* f) {
           "Options:\n"
           "  -o, --output <OUTPUT>    Output image name [env: OUTPUT=] [default: render.png]\n"
           "  -q, --quiet              No progress bar printed\n"
-          "  -v, --viewer             Display a viewer (accepted, ignored on the GPU path)\n"
+          "  -v, --viewer             Display a viewer (headless: the output file is refreshed after every sample batch)\n"
           "      --debug-textures     Generate debug textures\n"
           "  -p, --profile <PROFILE>  A path to the yaml file containing all the rendering profile information [env: PROFILE=]\n"
           "      --device <N>         HIP device ordinal [default: 0]\n"
@@ -62,6 +62,17 @@ struct Progress {
     std::chrono::steady_clock::time_point start;
 };
 
+// -v / --viewer on a headless node: the viewer feed (renderer/mod.rs:133-141, renderer/viewer.rs) becomes a
+// progressively refreshed output file — after every sample batch the image of the samples done so far.
+struct Preview {
+    std::string path;
+    uint32_t width, height;
+};
+void on_preview(const uint8_t* rgb8, uint64_t n_pixels, uint32_t, uint32_t, void* user) {
+    Preview* v = (Preview*)user;
+    if (n_pixels == (uint64_t)v->width * v->height) pth_png_write_rgb8(v->path.c_str(), v->width, v->height, rgb8);
+}
+
 void on_progress(uint32_t done, uint32_t total, void* user) {
     Progress* p = (Progress*)user;
     if (p->quiet) return;
@@ -74,7 +85,7 @@ void on_progress(uint32_t done, uint32_t total, void* user) {
 
 int run_render(int argc, char** argv) {
     std::string input, output, profile_path;
-    bool have_output = false, have_profile = false, quiet = false, debug_textures = false, stats = false;
+    bool have_output = false, have_profile = false, quiet = false, debug_textures = false, stats = false, viewer = false;
     int device = 0;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
@@ -100,9 +111,8 @@ int run_render(int argc, char** argv) {
             profile_path = a.substr(2);
             have_profile = true;
         } else if (a == "-q" || a == "--quiet") quiet = true;
-        else if (a == "-v" || a == "--viewer") {
-            // accepted and ignored: no window system on a headless GPU node
-        } else if (a == "-qv" || a == "-vq") quiet = true;
+        else if (a == "-v" || a == "--viewer") viewer = true;  // no window system here: progressive output file
+        else if (a == "-qv" || a == "-vq") quiet = viewer = true;
         else if (a == "--debug-textures") debug_textures = true;
         else if (a == "--stats") stats = true;
         else if (a == "--device" || a.rfind("--device=", 0) == 0) device = atoi(value("--device <N>").c_str());
@@ -162,7 +172,16 @@ int run_render(int argc, char** argv) {
     if (!quiet) {
         opts.progress = on_progress;
         opts.progress_user = &prog;
-        opts.sample_batch = profile.samples > 16 ? (profile.samples + 15) / 16 : 1;  // ~16 progress ticks
+    }
+    if (!quiet || viewer) opts.sample_batch = profile.samples > 16 ? (profile.samples + 15) / 16 : 1;  // ~16 ticks
+    Preview pv{output, profile.width, profile.height};
+    if (viewer) {
+        size_t dot = output.find_last_of('.');
+        std::string ext = dot == std::string::npos ? "" : output.substr(dot + 1);
+        if (ext == "png" || ext == "PNG") {
+            opts.preview = on_preview;
+            opts.preview_user = &pv;
+        }
     }
     std::vector<uint8_t> rgb((size_t)profile.width * profile.height * 3);
     if (pt_render(scene, &profile, &opts, rgb.data(), nullptr) != PT_OK) die(pt_last_error());

@@ -39,6 +39,19 @@ def test_cli_bad_profile_and_env(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_viewer_flag_refreshes_the_output(tmp_path, pta, gpu_scene_cache):
+    import numpy as np
+    from PIL import Image
+    prof = tmp_path / "p.yml"
+    prof.write_text("resolution: {width: 64, height: 48}\nsamples: 40\nbounces: 2\n")
+    out = tmp_path / "v.png"
+    r = run("render", str(SCENES / "cube" / "scene.isf"), "-q", "-v", "-p", str(prof), "-o", str(out))
+    assert r.returncode == 0, r.stderr
+    rgb, _ = gpu_scene_cache("cube").render(pta.Profile.make(64, 48, 40, 2))
+    assert np.array_equal(np.asarray(Image.open(out)).reshape(-1, 3), rgb)
+
+
+@pytest.mark.gpu
 def test_cli_debug_textures(tmp_path, pta, gpu_scene_cache):
     import numpy as np
     from PIL import Image

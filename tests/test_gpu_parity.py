@@ -330,6 +330,24 @@ def test_debug_textures_without_hits_write_nothing(pta, oracle, tmp_path):
     assert oracle.OracleScene(scene.desc, oracle.PTO_BVH).debug_render(32, 16) == {}
 
 
+def test_progressive_preview_matches_partial_renders(pta, gpu_scene_cache):
+    """Viewer feed (renderer/mod.rs:133-141): after k of N samples the preview is post_processing(sum_k / k); the
+    last preview is the final image and the preview hook does not disturb the render."""
+    g = gpu_scene_cache("reflection")
+    prof = pta.Profile.make(96, 64, 12, 3)
+    seen = []
+
+    def preview(rgb8, n_pixels, done, total, user):
+        seen.append((done, total, np.ctypeslib.as_array(rgb8, (n_pixels, 3)).copy()))
+
+    rgb, acc = g.render(prof, pta.Opts.make(sample_batch=5, preview=preview))
+    assert [d for d, _, _ in seen] == [5, 10, 12] and all(t == 12 for _, t, _ in seen)
+    assert np.array_equal(seen[-1][2], rgb)          # the last preview is the final image
+    assert not np.array_equal(seen[0][2], rgb)       # earlier ones are noisier
+    rgb_plain, acc_plain = g.render(prof)
+    assert np.array_equal(rgb, rgb_plain) and np.array_equal(acc.view(np.uint32), acc_plain.view(np.uint32))
+
+
 def test_host_buffer_errors(pta, scene_cache, gpu_scene_cache):
     g = gpu_scene_cache("cube")
     with pytest.raises(pta.PtError):
