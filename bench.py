@@ -176,8 +176,8 @@ def main():
         trace_bytes = counters["segments"] * 80 + counters["trace_nodes"] * 8 + counters["trace_tris"] * 36
         bytes_per_launch = trace_bytes / max(1, n_launch // args.steps)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        kernel_total = sum(stage_ms[k] for k in ("generate_ms", "trace_ms", "shade_ms", "shadow_ms", "accumulate_ms",
-                                                 "postprocess_ms")) / args.steps
+        # wall time of the kernel pipeline (the shadow casts overlap the next trace, so the stages do not add up)
+        kernel_total = stage_ms["total_ms"] / args.steps
         pipeline = ceil_b * n_local * args.spp / (kernel_total * 1e-3) / 1e9
         traffic = None
         tf = ROOT / "profiles" / "latest_traffic.json"
@@ -188,8 +188,10 @@ def main():
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        copy_gbs = pta.measure_copy_bandwidth(local_rank, 2 << 30, 5)   # achievable HBM rate on this box
         roofline = {"bound": "hbm", "kernel": "k_wf_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_launch // args.steps,
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
                     "pipeline": {"algorithmic_bytes_per_sample": round(ceil_b, 1),

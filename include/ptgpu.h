@@ -313,6 +313,12 @@ int pt_rng_words(int device, const uint64_t* seeds, uint64_t n_seeds, uint32_t n
  * against glibc): fn 0 = powf(x, 1/2.2f), 1 = acosf, 2 = sinf, 3 = cosf. */
 int pt_eval_math(int device, int fn, const float* x, uint64_t n, float* out);
 
+/* Measurement aid for the roofline ("achievable-copy figure with a
+ * stream kernel on the box"): copies `bytes` of device memory with a plain
+ * 16-byte-per-lane grid-stride kernel `reps` times and returns the best
+ * read+write rate in GB/s (2 * bytes / time).  No reference counterpart. */
+int pt_measure_copy_bandwidth(int device, uint64_t bytes, uint32_t reps, double* gb_per_s);
+
 const char* pt_last_error(void);
 const char* pt_version(void);
 

@@ -416,6 +416,24 @@ __global__ __launch_bounds__(256) void k_rng(const uint64_t* __restrict__ seeds,
     for (uint32_t w = 0; w < n_words; ++w) out[i * n_words + w] = pt_rng_next_u32(rng, slab, threadIdx.x);
 }
 
+// plain streaming copy, 16 B per lane per step: the achievable-HBM yardstick of the roofline
+typedef float pt_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ src4, float4* __restrict__ dst4, uint64_t n) {
+    const pt_v4f* src = (const pt_v4f*)src4;
+    pt_v4f* dst = (pt_v4f*)dst4;
+    uint64_t i = (uint64_t)blockIdx.x * 1024u + threadIdx.x;   // 4 independent 16-byte loads in flight per lane
+    if (i + 768u < n) {
+        pt_v4f a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + 256u);
+        pt_v4f c = __builtin_nontemporal_load(src + i + 512u), d = __builtin_nontemporal_load(src + i + 768u);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + 256u);
+        __builtin_nontemporal_store(c, dst + i + 512u);
+        __builtin_nontemporal_store(d, dst + i + 768u);
+    } else {
+        for (; i < n; i += 256u) dst[i] = src[i];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_math(int fn, const float* __restrict__ x, uint64_t n, float* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -504,7 +522,14 @@ struct pt_scene {
     mutable pt_timing timing{};
     mutable pt_counters counters{};
     mutable DeviceBuffer accum_scratch, tile_table, counter_buf, staging_buf, rng_buf, work_counter;
-    mutable DeviceBuffer wf_queue[2], wf_hits, wf_shadow, wf_contrib, wf_ctr;
+    // The queues of the chunk of work items in flight.  The shadow casts of bounce b run on a side stream
+    // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
+    struct WfPipe {
+        DeviceBuffer queue[2], hits, shadow, contrib, ctr;
+        hipStream_t side = nullptr;
+        hipEvent_t ev_shade = nullptr, ev_shadow = nullptr;
+    };
+    mutable WfPipe pipe;
     mutable int persist_blocks = 0, trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
     mutable std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> tile_key{0, 0, 0, 0, 0, 0};
     mutable std::vector<hipEvent_t> events;
@@ -513,6 +538,9 @@ struct pt_scene {
         (void)hipSetDevice(device);
         for (void* p : allocations) (void)hipFree(p);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {pipe.ev_shade, pipe.ev_shadow})
+            if (e) (void)hipEventDestroy(e);
+        if (pipe.side) (void)hipStreamDestroy(pipe.side);
     }
     template <class T>
     const T* upload(const T* host, size_t count) {
@@ -790,6 +818,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         const char* e = getenv("PT_WF_CHUNK");
         return (uint32_t)(e && *e ? atof(e) : 128.0 * 1024 * 1024);
     }();
+    static const bool wf_overlap = [] {    // shadow(b) on a side stream beside trace(b+1); PT_WF_OVERLAP=0 serialises
+        const char* e = getenv("PT_WF_OVERLAP");
+        return e && *e ? atoi(e) != 0 : true;
+    }();
     static const uint32_t wf_refill = [] {
         const char* e = getenv("PT_WF_REFILL");
         return (uint32_t)(e && *e ? atoi(e) : 16);
@@ -797,6 +829,14 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     static const uint32_t wf_walk = [] {
         const char* e = getenv("PT_WF_WALK");
         return (uint32_t)(e && *e ? atoi(e) : 20);
+    }();
+    static const uint32_t wf_refill_shadow = [] {
+        const char* e = getenv("PT_WF_REFILL_SHADOW");
+        return (uint32_t)(e && *e ? atoi(e) : 0);
+    }();
+    static const uint32_t wf_walk_shadow = [] {
+        const char* e = getenv("PT_WF_WALK_SHADOW");
+        return (uint32_t)(e && *e ? atoi(e) : 12);
     }();
     if (s.n_cu == 0) HIP_CHECK(hipDeviceGetAttribute(&s.n_cu, hipDeviceAttributeMultiprocessorCount, s.device));
     uint32_t batch = o.sample_batch ? o.sample_batch : p.samples;
@@ -839,26 +879,33 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 }
             }
         }
-        s.wf_queue[0].ensure((size_t)cap * 64u);
-        s.wf_queue[1].ensure((size_t)cap * 64u);
-        s.wf_hits.ensure((size_t)cap * 16u);
-        s.wf_shadow.ensure((size_t)cap * 64u);
-        s.wf_contrib.ensure((size_t)cap * 16u * std::max(1u, s.dev.n_lights));
-        s.wf_ctr.ensure(sizeof(WfCounters) * (p.bounces + 3));
+        pt_scene::WfPipe& w = s.pipe;
+        w.queue[0].ensure((size_t)cap * 64u);
+        w.queue[1].ensure((size_t)cap * 64u);
+        w.hits.ensure((size_t)cap * 16u);
+        w.shadow.ensure((size_t)cap * 64u);
+        w.contrib.ensure((size_t)cap * 16u * std::max(1u, s.dev.n_lights));
+        w.ctr.ensure(sizeof(WfCounters) * (p.bounces + 3));
+        if (wf_overlap && !w.side) {
+            HIP_CHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&w.ev_shade, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&w.ev_shadow, hipEventDisableTiming));
+        }
     }
     uint32_t blocks = tm.n_local_tiles * (o.tile_w * o.tile_h / 256u);
     size_t ev = 0;
     uint32_t launches = 0, stage_launches = 0;
     // (stage id, first event index) of every timed launch: 0 generate 1 trace 2 shade 3 shadow 4 accumulate 5 fused
     std::vector<std::pair<int, size_t>> marks;
+    hipStream_t stage_stream = stream;
     auto stage_begin = [&](int stage) {
         if (!timing) return;
         marks.emplace_back(stage, ev);
-        HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+        HIP_CHECK(hipEventRecord(get_event(s, ev++), stage_stream));
     };
     auto stage_end = [&]() {
         ++stage_launches;
-        if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+        if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stage_stream));
     };
     DevCounters* gctr = counting ? (DevCounters*)s.counter_buf.p : nullptr;
     for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
@@ -896,6 +943,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             ++launches;
         } else {
             uint32_t total_items = blocks64 * 64u * nb;
+            const pt_scene::WfPipe& pipe = s.pipe;
+            hipStream_t st_main = stream;
+            hipStream_t st_shadow = wf_overlap ? pipe.side : st_main;
             for (uint32_t base = 0; base < total_items; base += cap) {
                 WfParams W{};
                 W.P = P;
@@ -904,56 +954,71 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 W.cap = cap;
                 W.refill_min = std::max(1u, std::min(64u, wf_refill));
                 W.walk_steps = std::max(1u, wf_walk);
-                WfCounters* wctr = (WfCounters*)s.wf_ctr.p;
-                HIP_CHECK(hipMemsetAsync(wctr, 0, sizeof(WfCounters) * (p.bounces + 3), stream));
+                WfCounters* wctr = (WfCounters*)pipe.ctr.p;
+                HIP_CHECK(hipMemsetAsync(wctr, 0, sizeof(WfCounters) * (p.bounces + 3), st_main));
                 // bounce 0 of opaque scenes derives the camera rays in place (no generate kernel, no queue[0])
                 const bool fused_primary = !alpha;
                 if (!fused_primary) {
                     stage_begin(0);
-                    hipLaunchKernelGGL(k_wf_generate, dim3((W.n_items + 255u) / 256u), dim3(256), 0, stream, s.dev, W, d_tiles,
-                                       (float4*)s.wf_queue[0].p, wctr, gctr);
+                    hipLaunchKernelGGL(k_wf_generate, dim3((W.n_items + 255u) / 256u), dim3(256), 0, st_main, s.dev, W, d_tiles,
+                                       (float4*)pipe.queue[0].p, wctr, gctr);
                     HIP_CHECK(hipGetLastError());
                     stage_end();
                 }
                 for (uint32_t b = 0; b <= p.bounces; ++b) {
                     W.bounce = b;
-                    float4* q_in = (float4*)s.wf_queue[b & 1].p;
-                    float4* q_out = (float4*)s.wf_queue[(b + 1) & 1].p;
+                    float4* q_in = (float4*)pipe.queue[b & 1].p;
+                    float4* q_out = (float4*)pipe.queue[(b + 1) & 1].p;
                     const bool prim = fused_primary && b == 0;
-#define PT_LAUNCH_ACP(kernel, grid, threads, ...)                                                                                     \
-    do {                                                                                                                              \
-        if (prim && counting) hipLaunchKernelGGL((kernel<false, true, true>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__);     \
-        else if (prim) hipLaunchKernelGGL((kernel<false, false, true>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__);           \
-        else if (alpha && counting) hipLaunchKernelGGL((kernel<true, true, false>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__); \
-        else if (alpha) hipLaunchKernelGGL((kernel<true, false, false>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__);          \
-        else if (counting) hipLaunchKernelGGL((kernel<false, true, false>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__);       \
-        else hipLaunchKernelGGL((kernel<false, false, false>), dim3(grid), dim3(threads), 0, stream, __VA_ARGS__);                    \
-        HIP_CHECK(hipGetLastError());                                                                                                 \
+#define PT_LAUNCH_ACP(kernel, grid, threads, ...)                                                                                      \
+    do {                                                                                                                               \
+        if (prim && counting) hipLaunchKernelGGL((kernel<false, true, true>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__);     \
+        else if (prim) hipLaunchKernelGGL((kernel<false, false, true>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__);           \
+        else if (alpha && counting) hipLaunchKernelGGL((kernel<true, true, false>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__); \
+        else if (alpha) hipLaunchKernelGGL((kernel<true, false, false>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__);          \
+        else if (counting) hipLaunchKernelGGL((kernel<false, true, false>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((kernel<false, false, false>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__);                    \
+        HIP_CHECK(hipGetLastError());                                                                                                  \
     } while (0)
-#define PT_LAUNCH_AC(kernel, grid, ...)                                                                         \
-    do {                                                                                                        \
-        if (alpha && counting) hipLaunchKernelGGL((kernel<true, true>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);    \
-        else if (alpha) hipLaunchKernelGGL((kernel<true, false>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);          \
-        else if (counting) hipLaunchKernelGGL((kernel<false, true>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);       \
-        else hipLaunchKernelGGL((kernel<false, false>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                    \
-        HIP_CHECK(hipGetLastError());                                                                           \
+#define PT_LAUNCH_AC(kernel, grid, ...)                                                                                  \
+    do {                                                                                                                 \
+        if (alpha && counting) hipLaunchKernelGGL((kernel<true, true>), dim3(grid), dim3(256), 0, st_shadow, __VA_ARGS__); \
+        else if (alpha) hipLaunchKernelGGL((kernel<true, false>), dim3(grid), dim3(256), 0, st_shadow, __VA_ARGS__);       \
+        else if (counting) hipLaunchKernelGGL((kernel<false, true>), dim3(grid), dim3(256), 0, st_shadow, __VA_ARGS__);    \
+        else hipLaunchKernelGGL((kernel<false, false>), dim3(grid), dim3(256), 0, st_shadow, __VA_ARGS__);                 \
+        HIP_CHECK(hipGetLastError());                                                                                    \
     } while (0)
                     stage_begin(1);
-                    PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, 256, s.dev, W, d_tiles, q_in, (uint4*)s.wf_hits.p, wctr, gctr);
+                    PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, 256, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p, wctr, gctr);
                     stage_end();
                     ++launches;
+                    // shade(b) reads the colours shadow(b-1) patched and refills the shadow queue it consumed
+                    if (st_shadow != st_main && b > 0) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
                     stage_begin(2);
                     PT_LAUNCH_ACP(k_wf_shade, (uint32_t)(s.n_cu * 4), WF_SHADE_THREADS, s.dev, W, d_tiles, (const float4*)q_in,
-                                  (const uint4*)s.wf_hits.p, q_out, (float4*)s.wf_shadow.p, (float4*)s.wf_contrib.p,
+                                  (const uint4*)pipe.hits.p, q_out, (float4*)pipe.shadow.p, (float4*)pipe.contrib.p,
                                   (float*)s.staging_buf.p, wctr, gctr);
                     stage_end();
+                    if (st_shadow != st_main) {
+                        HIP_CHECK(hipEventRecord(pipe.ev_shade, st_main));
+                        HIP_CHECK(hipStreamWaitEvent(st_shadow, pipe.ev_shade, 0));
+                    }
+                    stage_stream = st_shadow;
                     stage_begin(3);
-                    PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, s.dev, W, (const float4*)s.wf_shadow.p,
-                                 (const float4*)s.wf_contrib.p, q_out, (float*)s.staging_buf.p, wctr, gctr);
+                    WfParams Ws = W;
+                    if (wf_refill_shadow) Ws.refill_min = std::min(64u, wf_refill_shadow);
+                    if (wf_walk_shadow) Ws.walk_steps = wf_walk_shadow;
+                    PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, s.dev, Ws, (const float4*)pipe.shadow.p,
+                                 (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, wctr, gctr);
                     stage_end();
+                    stage_stream = st_main;
+                    if (st_shadow != st_main) HIP_CHECK(hipEventRecord(pipe.ev_shadow, st_shadow));
 #undef PT_LAUNCH_ACP
 #undef PT_LAUNCH_AC
                 }
+                // the next chunk clears the counters and reuses the queues, accumulate reads the staging area:
+                // join the side stream
+                if (st_shadow != st_main) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
             }
         }
         if (mode >= 1) {
@@ -1271,6 +1336,36 @@ int pt_eval_math(int device, int fn, const float* x, uint64_t n, float* out) {
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());
         d_out.fetch(out, n);
+    });
+}
+
+int pt_measure_copy_bandwidth(int device, uint64_t bytes, uint32_t reps, double* gb_per_s) {
+    return guarded([&] {
+        if (!gb_per_s) fail(PT_ERR_INVALID, "pt_measure_copy_bandwidth: null argument");
+        if (bytes < 16 || reps == 0) fail(PT_ERR_INVALID, "pt_measure_copy_bandwidth: bytes >= 16 and reps >= 1 required");
+        select_device(device);
+        uint64_t n = bytes / 16;
+        Staged<float4> src(nullptr, n), dst(nullptr, n);
+        HIP_CHECK(hipMemset(src.d, 1, n * 16));
+        if (n > (1ull << 40)) fail(PT_ERR_INVALID, "pt_measure_copy_bandwidth: at most 16 TiB");
+        uint32_t grid = (uint32_t)((n + 1023) / 1024);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        float best = INFINITY;
+        for (uint32_t r = 0; r <= reps; ++r) {  // the first pass only touches the pages
+            HIP_CHECK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, 0, src.d, dst.d, n);
+            HIP_CHECK(hipEventRecord(e1, 0));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0 && ms < best) best = ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        HIP_CHECK(hipGetLastError());
+        *gb_per_s = 2.0 * (double)(n * 16) / ((double)best * 1e-3) / 1e9;
     });
 }
 

@@ -79,6 +79,15 @@ struct WfCounters {  // one set per bounce level, zeroed once per chunk
 #define WF_FLAG_TERMINATED 1u
 #define WF_FLAG_SPHERE 2u
 
+// Lane state of the persistent kernels, kept in ONE vector register: bool flags live in scalar lane
+// masks, and every divergent update of such a mask costs an andn2 / and / or triple on the scalar
+// unit that all waves of the CU share (the walk loop spent ~35 of its ~130 instructions there).
+#define WF_LANE_WALK 0u   // walking the tree (trav_step returns these three)
+#define WF_LANE_LEAF 1u   // parked at a non-empty leaf
+#define WF_LANE_DONE 2u   // the cast has no further segment
+#define WF_LANE_IDLE 3u   // no cast in progress
+PT_D bool wf_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 PT_D uint32_t wf_lane_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -230,7 +239,7 @@ PT_D bool trav_pop(Trav& T, const TravStack& st, float limit) {
 // the branchy form of this step was ~110 instructions, more than half of them scalar mask juggling,
 // and took ~4400 cycles per wave-step whatever the scene size (profiles/r01_f_trace_stamps.txt).
 template <bool COUNT>
-PT_D int trav_step(const DevScene& S, Trav& T, const TravStack& st, float limit, LocalCtr& lc) {
+PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float limit, LocalCtr& lc) {
     const uint2 nd = S.kd_nodes[T.node];
     if (COUNT) lc.nodes++;
     const uint32_t axis = nd.y & 3u;
@@ -255,13 +264,13 @@ PT_D int trav_step(const DevScene& S, Trav& T, const TravStack& st, float limit,
             T.tmax = tplane;
         }
         T.node = only_second ? second : first;
-        return 0;
+        return WF_LANE_WALK;
     }
     if (nd.y >> 2) {
         T.leaf = nd;
-        return 1;
+        return WF_LANE_LEAF;
     }
-    return trav_pop(T, st, limit) ? 0 : 2;  // empty leaf: straight on to the next segment
+    return trav_pop(T, st, limit) ? WF_LANE_WALK : WF_LANE_DONE;  // empty leaf: straight on to the next segment
 }
 
 // Closest-hit candidate update for one leaf (same acceptance rule as next_hit()).
@@ -437,7 +446,8 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
     bool have_kept = false;
     float t_prev = -INFINITY;
     uint32_t ord_prev = 0, idx = 0, seed_lo = 0, seed_hi = 0, draw = 0;
-    bool active = false, exhausted = false, at_leaf = false, cast_done = false;
+    bool active = false, exhausted = false;
+    uint32_t lstate = WF_LANE_IDLE;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     uint32_t cast_nodes0 = 0;
     WaveFetch wf = {0u, 0u, false};
@@ -445,7 +455,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
     // the current cast has no further segment: best = next entry of the sorted hit list (or none)
     // (called from ONE place per loop iteration to keep the kernel's register footprint small)
     auto complete = [&]() {
-        cast_done = false;
+        lstate = WF_LANE_WALK;
         bool hit = best.pid != 0xffffffffu;
         bool finished = true;
         if (ALPHA && hit) {
@@ -492,6 +502,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
                 q[3] = make_float4(q3.x, __uint_as_float(packed), q3.z, q3.w);
             }
             active = false;
+            lstate = WF_LANE_IDLE;
         }
     };
 
@@ -551,9 +562,8 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
                 best.ord = 0xffffffffu;
                 best.pid = 0xffffffffu;
                 active = true;
-                at_leaf = false;
                 // outside the image / misses the scene box: answered as "no hit" below
-                cast_done = !valid_item || !trav_start(S, T, o, d, 0.f);
+                lstate = (!valid_item || !trav_start(S, T, o, d, 0.f)) ? WF_LANE_DONE : WF_LANE_WALK;
             }
         }
         WF_STAMP(st_refill);
@@ -563,33 +573,28 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
         }
         // ---- phase A: walk
         for (uint32_t k = 0; k < W.walk_steps; ++k) {
-            bool walking = active && !at_leaf && !cast_done;
-            if (!__any(walking)) break;
+            const bool walking = lstate == WF_LANE_WALK;
+            if (!wf_any(walking)) break;
 #ifdef WF_STAMPS
             st_walk_lanes += __popcll(__ballot(walking));
             st_walk_steps++;
 #endif
-            if (walking) {
-                int r = trav_step<COUNT>(S, T, st, best.key, lc);
-                at_leaf = r == 1;
-                cast_done = r == 2;
-            }
+            if (walking) lstate = trav_step<COUNT>(S, T, st, best.key, lc);
         }
         WF_STAMP(st_walk);
         // ---- phase B: primitives of the parked leaves
 #ifdef WF_STAMPS
-        if (__any(active && at_leaf)) {
-            st_leaf_lanes += __popcll(__ballot(active && at_leaf));
+        if (__any(lstate == WF_LANE_LEAF)) {
+            st_leaf_lanes += __popcll(__ballot(lstate == WF_LANE_LEAF));
             st_leaf_runs++;
         }
 #endif
-        if (active && at_leaf) {
+        if (lstate == WF_LANE_LEAF) {
             leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc);
-            at_leaf = false;
-            cast_done = !trav_pop(T, st, best.key);
+            lstate = trav_pop(T, st, best.key) ? WF_LANE_WALK : WF_LANE_DONE;
         }
         WF_STAMP(st_leaf);
-        if (active && cast_done) complete();
+        if (lstate == WF_LANE_DONE) complete();
         WF_STAMP(st_done);
     }
 #ifdef WF_STAMPS
@@ -799,7 +804,8 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
     best.key = INFINITY;
     best.ord = 0xffffffffu;
     best.pid = 0xffffffffu;
-    bool active = false, exhausted = false, at_leaf = false, cast_done = false, need_begin = false;
+    bool active = false, exhausted = false, need_begin = false;
+    uint32_t lstate = WF_LANE_IDLE;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     WaveFetch wf = {0u, 0u, false};
 
@@ -837,8 +843,10 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
             best.pid = 0xffffffffu;
             // opaque scenes: hits farther than the light cannot pass the range test
             limit = (!ALPHA && point) ? (ldist + 1e-4f) * 1.0001f : INFINITY;
-            at_leaf = false;
-            if (trav_start(S, T, so, sd, 0.f)) return true;
+            if (trav_start(S, T, so, sd, 0.f)) {
+                lstate = WF_LANE_WALK;
+                return true;
+            }
             add_light();  // the shadow ray misses the scene box: unoccluded
         }
         return false;
@@ -858,7 +866,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
     };
     // the current cast has no further segment (ONE call site per loop iteration)
     auto complete = [&]() {
-        cast_done = false;
+        lstate = WF_LANE_IDLE;
         if (ALPHA) {
             // best = next entry of the sorted list: attenuate, then look for the following one
             bool more = best.pid != 0xffffffffu;
@@ -890,7 +898,10 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
                 best.ord = 0xffffffffu;
                 best.pid = 0xffffffffu;
                 if (COUNT) lc.restarts++;
-                if (trav_start(S, T, T.o, T.d, next_start(t_prev, T.d))) return;  // keep walking
+                if (trav_start(S, T, T.o, T.d, next_start(t_prev, T.d))) {  // keep walking
+                    lstate = WF_LANE_WALK;
+                    return;
+                }
             }
         } else if (blocked) {
             rad = rad * 0.0f;
@@ -923,7 +934,6 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
         }
         if (active && need_begin) {  // the ONE place a light's shadow cast starts
             need_begin = false;
-            cast_done = false;
             if (!begin_light()) retire();
         }
         if (!__any(active)) {
@@ -932,17 +942,12 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
         }
         // ---- phase A: walk
         for (uint32_t k = 0; k < W.walk_steps; ++k) {
-            bool walking = active && !at_leaf && !cast_done;
-            if (!__any(walking)) break;
-            if (walking) {
-                int r = trav_step<COUNT>(S, T, st, ALPHA ? best.key : limit, lc);
-                at_leaf = r == 1;
-                cast_done = r == 2;
-            }
+            const bool walking = lstate == WF_LANE_WALK;
+            if (!wf_any(walking)) break;
+            if (walking) lstate = trav_step<COUNT>(S, T, st, ALPHA ? best.key : limit, lc);
         }
         // ---- phase B
-        if (active && at_leaf) {
-            at_leaf = false;
+        if (lstate == WF_LANE_LEAF) {
             if (!ALPHA) {
                 // every opacity is exactly 1: any hit inside the light's range blocks it
                 const float4* lp = S.leaf_prims + (size_t)T.leaf.x * 3;
@@ -970,13 +975,13 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
                         }
                     }
                 }
-                cast_done = blocked || !trav_pop(T, st, limit);
+                lstate = (blocked || !trav_pop(T, st, limit)) ? WF_LANE_DONE : WF_LANE_WALK;
             } else {
                 leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc);
-                cast_done = !trav_pop(T, st, best.key);
+                lstate = trav_pop(T, st, best.key) ? WF_LANE_WALK : WF_LANE_DONE;
             }
         }
-        if (active && cast_done) complete();
+        if (lstate == WF_LANE_DONE) complete();
     }
     if (COUNT) {
         atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);

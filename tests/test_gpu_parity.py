@@ -356,3 +356,11 @@ def test_host_buffer_errors(pta, scene_cache, gpu_scene_cache):
         g.render(pta.Profile.make(16, 16, 0, 1))
     with pytest.raises(pta.PtError):
         g.render(pta.Profile.make(16, 16, 1, 1), pta.Opts.make(shard_rank=3, shard_count=2))
+
+
+def test_copy_bandwidth_yardstick(pta):
+    """pt_measure_copy_bandwidth: a plain copy must land between 1 and 8 TB/s on an MI355X."""
+    gbs = pta.measure_copy_bandwidth(0, 1 << 28, 3)
+    assert 1000.0 < gbs < 8000.0, gbs
+    with pytest.raises(pta.PtError):
+        pta.measure_copy_bandwidth(0, 8, 1)
