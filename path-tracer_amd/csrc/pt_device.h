@@ -51,6 +51,7 @@ struct DevScene {
     uint32_t n_lights;
     uint32_t n_prims;
     uint32_t n_nodes;
+    uint32_t n_node_slots;   // entries of kd_nodes (device layout, >= n_nodes)
     uint32_t has_translucent;
     float bounds_min[3];
     float bounds_max[3];

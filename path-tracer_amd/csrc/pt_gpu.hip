@@ -525,7 +525,7 @@ struct pt_scene {
     // The queues of the chunk of work items in flight.  The shadow casts of bounce b run on a side stream
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
-        DeviceBuffer queue[2], hits, shadow, contrib, ctr;
+        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng;
         hipStream_t side = nullptr;
         hipEvent_t ev_shade = nullptr, ev_shadow = nullptr;
     };
@@ -720,6 +720,7 @@ void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
     D.n_lights = d.n_lights;
     D.n_prims = (uint32_t)n_prims;
     D.n_nodes = (uint32_t)kd.n_nodes;
+    D.n_node_slots = (uint32_t)tre.size();
     D.has_translucent = translucent ? 1u : 0u;
     for (int a = 0; a < 3; ++a) {
         float pad = 1e-4f * std::max(fabsf(kd.bounds_min[a]), fabsf(kd.bounds_max[a])) + 1e-5f;
@@ -886,6 +887,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         w.shadow.ensure((size_t)cap * 64u);
         w.contrib.ensure((size_t)cap * 16u * std::max(1u, s.dev.n_lights));
         w.ctr.ensure(sizeof(WfCounters) * (p.bounces + 3));
+        w.rng.ensure((size_t)cap * 32u);   // words 0-7 of every item's ChaCha block, two 16-byte planes
         if (wf_overlap && !w.side) {
             HIP_CHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_shade, hipEventDisableTiming));
@@ -958,13 +960,15 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 HIP_CHECK(hipMemsetAsync(wctr, 0, sizeof(WfCounters) * (p.bounces + 3), st_main));
                 // bounce 0 of opaque scenes derives the camera rays in place (no generate kernel, no queue[0])
                 const bool fused_primary = !alpha;
-                if (!fused_primary) {
-                    stage_begin(0);
+                stage_begin(0);
+                if (!fused_primary)
                     hipLaunchKernelGGL(k_wf_generate, dim3((W.n_items + 255u) / 256u), dim3(256), 0, st_main, s.dev, W, d_tiles,
-                                       (float4*)pipe.queue[0].p, wctr, gctr);
-                    HIP_CHECK(hipGetLastError());
-                    stage_end();
-                }
+                                       (float4*)pipe.queue[0].p, (uint4*)pipe.rng.p, wctr, gctr);
+                else
+                    hipLaunchKernelGGL(k_wf_rng, dim3((W.n_items + 255u) / 256u), dim3(256), 0, st_main, s.dev, W, d_tiles,
+                                       (uint4*)pipe.rng.p);
+                HIP_CHECK(hipGetLastError());
+                stage_end();
                 for (uint32_t b = 0; b <= p.bounces; ++b) {
                     W.bounce = b;
                     float4* q_in = (float4*)pipe.queue[b & 1].p;
@@ -989,14 +993,16 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         HIP_CHECK(hipGetLastError());                                                                                    \
     } while (0)
                     stage_begin(1);
-                    PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, 256, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p, wctr, gctr);
+                    PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, 256, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
+                                  (const uint4*)pipe.rng.p, wctr, gctr);
                     stage_end();
                     ++launches;
                     // shade(b) reads the colours shadow(b-1) patched and refills the shadow queue it consumed
                     if (st_shadow != st_main && b > 0) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
                     stage_begin(2);
                     PT_LAUNCH_ACP(k_wf_shade, (uint32_t)(s.n_cu * 4), WF_SHADE_THREADS, s.dev, W, d_tiles, (const float4*)q_in,
-                                  (const uint4*)pipe.hits.p, q_out, (float4*)pipe.shadow.p, (float4*)pipe.contrib.p,
+                                  (const uint4*)pipe.hits.p, (const uint4*)pipe.rng.p, q_out, (float4*)pipe.shadow.p,
+                                  (float4*)pipe.contrib.p,
                                   (float*)s.staging_buf.p, wctr, gctr);
                     stage_end();
                     if (st_shadow != st_main) {

@@ -620,21 +620,30 @@ PT_D f3 render_path(const DevScene& S, uint32_t bounces, f3 o, f3 d, PtRng& rng,
     return ps.color;
 }
 
-// Camera ray (mod.rs:107-124)
-PT_D void primary_ray(const DevScene& S, uint32_t x, uint32_t y, uint32_t width, uint32_t height, float r1, float r2,
-                      f3& o, f3& d) {
+// Camera ray (mod.rs:107-124), in two halves: the jittered screen position of a pixel sample and the
+// ray through a screen position (the wavefront integrator computes the first half once per item).
+PT_D void primary_screen(const DevScene& S, uint32_t x, uint32_t y, uint32_t width, uint32_t height, float r1, float r2,
+                         float& sx, float& sy) {
     float wf = (float)width, hf = (float)height;
     float ratio = wf / hf;
-    float sx = (float)x + r1;
+    sx = (float)x + r1;
     sx = sx / wf * 2.f - 1.f;
     sx *= S.tan_half_fov * ratio;
-    float sy = (float)y + r2;
+    sy = (float)y + r2;
     sy = 1.f - sy / hf * 2.f;
     sy *= S.tan_half_fov;
+}
+PT_D void primary_from_screen(const DevScene& S, float sx, float sy, f3& o, f3& d) {
     f3 dir = normalize3(mk3(sx, sy, -1.f));
     f3 c0 = ld3(S.cam_c0), c1 = ld3(S.cam_c1), c2 = ld3(S.cam_c2), c3 = ld3(S.cam_c3);
     d = c0 * dir.x + c1 * dir.y + c2 * dir.z + c3 * 0.0f;
     o = c3;
+}
+PT_D void primary_ray(const DevScene& S, uint32_t x, uint32_t y, uint32_t width, uint32_t height, float r1, float r2,
+                      f3& o, f3& d) {
+    float sx, sy;
+    primary_screen(S, x, y, width, height, r1, r2, sx, sy);
+    primary_from_screen(S, sx, sy, o, d);
 }
 
 // tonemap + gamma + u8 (tonemap.rs:15-54, mod.rs:335-353)

@@ -4,9 +4,10 @@
 // other inside one fused kernel (measured: 8 of 64 lanes active per VALU instruction there).
 //
 //   per chunk of work items (one item = one path sample, pt_gpu.hip decode_item):
-//     k_wf_generate                 ChaCha12 block (words 0,1) + camera ray -> queue[0]   (translucent scenes
-//                                   only: opaque scenes derive the camera ray inside the bounce-0 trace and
-//                                   shade kernels, template parameter PRIMARY)
+//     k_wf_rng                      ChaCha12 block 0 of every item, words 0-7 staged in two 16-byte planes
+//                                   (opaque scenes: the bounce-0 trace and shade kernels derive the camera
+//                                   ray in place from words 0,1 - template parameter PRIMARY)
+//     k_wf_generate                 the same plus the camera ray -> queue[0]   (translucent scenes only)
 //     for bounce = 0 .. bounces:
 //        k_wf_trace   (persistent)  ray_cast + alpha walk                   -> hit[i]
 //        k_wf_shade                 material, BRDF, next ray, termination   -> queue[b+1], shadow queue
@@ -15,7 +16,7 @@
 //
 // Queue records are 16-byte vectors read and written by consecutive lanes (coalesced):
 //   PathRec  64 B  q0 = (o.xyz, d.x)  q1 = (d.yz, thr.xy)  q2 = (thr.z, color.xyz)
-//                  q3 = (seed_lo, draw_idx | bounce << 16, out_slot, seed_hi)   seed = StdRng seed of the sample
+//                  q3 = (item, draw_idx | bounce << 16, out_slot, 0)   item = work item of the chunk (-> RNG words)
 //   HitRec   16 B  (pid | flags << 28 ... see pack_hit, key, u, v)
 //   ShadowRec 64 B s0 = (pos.xyz, gn.x) s1 = (gn.yz, uv.xy) s2 = (color.xyz, bits(next_index))
 //                  s3 = (bits(out_slot), bits(flags), 0, 0)     + contrib[light][k] float4
@@ -164,34 +165,75 @@ struct Trav {
     f3 o, d, inv;
     float tmin, tmax, key_scale;
     uint32_t node;
+    uint32_t dneg;   // bit a: d[a] <= 0 (the tie rule of the child order)
     int sp;
     uint2 leaf;   // the non-empty leaf the lane is holding (valid when trav_step returned 1)
 };
 
+// The LDS column is typed with its address space: a generic pointer that may come from either LDS
+// or scratch makes the compiler merge the two loads of a pop into flat (generic) loads.
+typedef __attribute__((address_space(3))) unsigned long long wf_lds_u64;
 struct TravStack {
-    uint2* lds;            // this thread's column: entry e at lds[e * WF_THREADS]
+    wf_lds_u64* lds;       // this thread's column: entry e at lds[e * WF_THREADS] = node | bits(tmax) << 32
     uint32_t* ov_node;     // overflow (scratch)
     float* ov_tmax;
+    const wf_lds_u64* top; // the first WF_LDS_NODES node slots (the top treelets of the tree), one copy per workgroup
 };
 
-// The LDS part is always addressed as LDS and the (rare) overflow has its own branch: a merged
-// "pointer select" makes the compiler fall back to flat (generic) loads on the hot path.
+// Top of the KD-tree staged in LDS.  A walk step is one 8-byte node fetch per lane at ~44 scattered
+// addresses per wavefront; the vector memory path serves those at a few cycles per lane whether they
+// hit L1 or not (profiles/r01_f_trace_stamps.txt), and every ray passes through the top levels, so the
+// first node slots - the device layout is breadth-first over 4-level treelets - are read from LDS.
+#ifndef WF_LDS_NODES
+#define WF_LDS_NODES 1024
+#endif
+PT_D void wf_load_tree_top(const DevScene& S, unsigned long long* lds_top) {
+    const uint32_t n = S.n_node_slots < (uint32_t)WF_LDS_NODES ? S.n_node_slots : (uint32_t)WF_LDS_NODES;
+    for (uint32_t i = threadIdx.x; i < n; i += WF_THREADS) {
+        uint2 g = S.kd_nodes[i];
+        lds_top[i] = (unsigned long long)g.x | ((unsigned long long)g.y << 32);
+    }
+    __syncthreads();
+}
+
+// v_cndmask on a lane mask.  Written as an instruction because the optimiser turns a `?:` chain over
+// the three axes into a scratch array indexed by the axis (scratch loads on the hottest path).
+PT_D float wf_select(unsigned long long mask, float if_set, float if_clear) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
+
+// The LDS part is always addressed as LDS.  The (rare) overflow into scratch sits behind a
+// wave-uniform branch: a per-lane "pointer select" makes the compiler fall back to flat (generic)
+// loads on the hot path, and a per-lane branch costs an exec-mask save / restore on every step.
 PT_D void stack_push(const TravStack& st, int sp, uint32_t node, float tmax) {
-    if (sp < WF_LDS_STACK) {
-        st.lds[sp * WF_THREADS] = make_uint2(node, __float_as_uint(tmax));
+    const unsigned long long e = (unsigned long long)node | ((unsigned long long)__float_as_uint(tmax) << 32);
+    if (__builtin_expect(wf_any(sp >= WF_LDS_STACK), 0)) {
+        if (sp >= WF_LDS_STACK) {
+            st.ov_node[sp - WF_LDS_STACK] = node;
+            st.ov_tmax[sp - WF_LDS_STACK] = tmax;
+        } else {
+            st.lds[sp * WF_THREADS] = e;
+        }
     } else {
-        st.ov_node[sp - WF_LDS_STACK] = node;
-        st.ov_tmax[sp - WF_LDS_STACK] = tmax;
+        st.lds[sp * WF_THREADS] = e;
     }
 }
 PT_D void stack_get(const TravStack& st, int sp, uint32_t& node, float& tmax) {
-    int slot = sp < WF_LDS_STACK ? sp : WF_LDS_STACK - 1;
-    uint2 e = st.lds[slot * WF_THREADS];
-    node = e.x;
-    tmax = __uint_as_float(e.y);
-    if (sp >= WF_LDS_STACK) {
-        node = st.ov_node[sp - WF_LDS_STACK];
-        tmax = st.ov_tmax[sp - WF_LDS_STACK];
+    if (__builtin_expect(wf_any(sp >= WF_LDS_STACK), 0)) {
+        if (sp >= WF_LDS_STACK) {
+            node = st.ov_node[sp - WF_LDS_STACK];
+            tmax = st.ov_tmax[sp - WF_LDS_STACK];
+        } else {
+            const unsigned long long e = st.lds[sp * WF_THREADS];
+            node = (uint32_t)e;
+            tmax = __uint_as_float((uint32_t)(e >> 32));
+        }
+    } else {
+        const unsigned long long e = st.lds[sp * WF_THREADS];
+        node = (uint32_t)e;
+        tmax = __uint_as_float((uint32_t)(e >> 32));
     }
 }
 
@@ -201,6 +243,7 @@ PT_D bool trav_start(const DevScene& S, Trav& T, f3 o, f3 d, float t_start) {
     T.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float dlen = mag3(d);
     T.key_scale = dlen < 1.0f ? dlen : 1.0f;
+    T.dneg = (d.x <= 0.f ? 1u : 0u) | (d.y <= 0.f ? 2u : 0u) | (d.z <= 0.f ? 4u : 0u);
     float tmin = t_start, tmax = INFINITY;
     const float oa[3] = {o.x, o.y, o.z}, ia[3] = {T.inv.x, T.inv.y, T.inv.z};
 #pragma unroll
@@ -240,23 +283,28 @@ PT_D bool trav_pop(Trav& T, const TravStack& st, float limit) {
 // and took ~4400 cycles per wave-step whatever the scene size (profiles/r01_f_trace_stamps.txt).
 template <bool COUNT>
 PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float limit, LocalCtr& lc) {
-    const uint2 nd = S.kd_nodes[T.node];
+    // LDS read first and unconditional (clamped index): the global fetch of the deeper lanes must not
+    // wait behind it, nor the other way round
+    const uint32_t top_slot = T.node < (uint32_t)WF_LDS_NODES ? T.node : (uint32_t)WF_LDS_NODES - 1u;
+    const unsigned long long e = st.top[top_slot];
+    uint2 nd = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
+    if (T.node >= (uint32_t)WF_LDS_NODES) nd = S.kd_nodes[T.node];
     if (COUNT) lc.nodes++;
     const uint32_t axis = nd.y & 3u;
     if (axis != 3u) {
         const float split = __uint_as_float(nd.x);
-        // all three axes evaluated, result selected by value (see the note on scratch arrays above)
-        const float tp0 = (split - T.o.x) * T.inv.x, tp1 = (split - T.o.y) * T.inv.y, tp2 = (split - T.o.z) * T.inv.z;
-        const bool bf0 = (T.o.x < split) | ((T.o.x == split) & (T.d.x <= 0.f));
-        const bool bf1 = (T.o.y < split) | ((T.o.y == split) & (T.d.y <= 0.f));
-        const bool bf2 = (T.o.z < split) | ((T.o.z == split) & (T.d.z <= 0.f));
-        const bool ax0 = axis == 0u, ax1 = axis == 1u;
-        const float tplane = ax0 ? tp0 : (ax1 ? tp1 : tp2);
-        const bool below_first = ax0 ? bf0 : (ax1 ? bf1 : bf2);
+        const unsigned long long ax0 = __builtin_amdgcn_uicmp(axis, 0u, 32), ax1 = __builtin_amdgcn_uicmp(axis, 1u, 32);  // EQ
+        const float o_a = wf_select(ax0, T.o.x, wf_select(ax1, T.o.y, T.o.z));
+        const float i_a = wf_select(ax0, T.inv.x, wf_select(ax1, T.inv.y, T.inv.z));
+        const float tplane = (split - o_a) * i_a;
+        // below child first iff o < split, or o == split and d <= 0
+        const uint32_t dn = (T.dneg >> axis) & 1u;
+        const uint32_t bf = (o_a < split ? 1u : 0u) | (o_a == split ? dn : 0u);
         const uint32_t pair = nd.y >> 2;  // children = pair (below), pair + 1 (above)
-        const uint32_t first = pair + (below_first ? 0u : 1u), second = pair + (below_first ? 1u : 0u);
-        const bool only_first = (tplane > T.tmax * PT_EXIT_REL + PT_EXIT_ABS) | (tplane <= 0.f);
-        const bool only_second = !only_first & (tplane < T.tmin * (2.f - PT_EXIT_REL) - PT_EXIT_ABS);
+        const uint32_t second = pair + bf, first = pair + (bf ^ 1u);
+        // the slack of the exit tests is the traversal's own (not reference arithmetic): fused
+        const bool only_first = (tplane > __builtin_fmaf(T.tmax, PT_EXIT_REL, PT_EXIT_ABS)) | (tplane <= 0.f);
+        const bool only_second = !only_first & (tplane < __builtin_fmaf(T.tmin, 2.f - PT_EXIT_REL, -PT_EXIT_ABS));
         const bool both = !(only_first | only_second);  // also for a NaN plane parameter: conservative
         if (both) {
             stack_push(st, T.sp, second, T.tmax);
@@ -344,18 +392,18 @@ PT_D bool unpack_hit(uint4 r, RawHit& h) {
     return true;
 }
 
+PT_D float wf_rng_float(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0f); }  // rng.gen::<f32>()
+
 // ---------------------------------------------------------------------------
 // generate: RNG block + camera ray for every valid item of the chunk
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wf_generate(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
-                                                     float4* __restrict__ queue, WfCounters* __restrict__ ctr,
-                                                     DevCounters* __restrict__ gctr) {
+                                                     float4* __restrict__ queue, uint4* __restrict__ rng_planes,
+                                                     WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     // No compaction here: queue[0] slot = item (the only invalid items are the 8x8 blocks that
     // hang over the image border); an invalid item is a record with out_slot = ~0 that the
     // trace kernel answers with "no hit" and the shade kernel drops.
-    // The ChaCha block is NOT staged: 64 B per item was half of this kernel's HBM traffic, while
-    // a path uses 3 words on average.  The consumers (shade, alpha walk) are memory-bound and
-    // re-derive the block from the 64-bit seed carried in the record (~700 integer ops).
+    // Words 0-7 of the item's ChaCha block are staged for the consumers (see k_wf_rng).
     uint32_t rel = blockIdx.x * 256u + threadIdx.x;
     if (rel == 0) ctr[0].queue_count = W.n_items;
     if (rel >= W.n_items) return;
@@ -378,43 +426,71 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevScene S, WfParams W, con
     float r1 = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
     float r2 = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
     f3 o, d;
-    primary_ray(S, it.x, it.y, W.P.width, W.P.height, r1, r2, o, d);
+    float sx, sy;
+    primary_screen(S, it.x, it.y, W.P.width, W.P.height, r1, r2, sx, sy);
+    primary_from_screen(S, sx, sy, o, d);
     uint32_t out_slot = (it.sample - 1u - W.P.sample_begin) * W.P.n_local + it.out_index;
     q[0] = make_float4(o.x, o.y, o.z, d.x);
     q[1] = make_float4(d.y, d.z, 1.f, 1.f);
     q[2] = make_float4(1.f, 0.f, 0.f, 0.f);
-    q[3] = make_float4(__uint_as_float((uint32_t)seed), __uint_as_float(2u), __uint_as_float(out_slot),
-                       __uint_as_float((uint32_t)(seed >> 32)));
+    q[3] = make_float4(__uint_as_float(rel), __uint_as_float(2u), __uint_as_float(out_slot), 0.f);
+    rng_planes[rel] = make_uint4(__float_as_uint(sx), __float_as_uint(sy), w[2], w[3]);
+    rng_planes[(size_t)W.cap + rel] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-// Camera ray of a work item from its first two RNG words (mod.rs:107-124).
-PT_D void item_primary_ray(const DevScene& S, const RenderParams& P, const ItemRef& it, uint32_t w0, uint32_t w1, f3& o,
-                           f3& d) {
-    float r1 = (float)(w0 >> 8) * (1.0f / 16777216.0f);
-    float r2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
-    primary_ray(S, it.x, it.y, P.width, P.height, r1, r2, o, d);
+// ---------------------------------------------------------------------------
+// rng: ChaCha12 block 0 of every item of the chunk, once, with every lane busy.  The block costs ~700
+// integer instructions; deriving it where it is consumed (in the refill of the bounce-0 trace at ~40 %
+// lane occupancy, again in the bounce-0 shade, again at every later bounce) was 15-20 % of all vector
+// instructions of a frame, and the trace / shade / shadow kernels are bound by instruction issue.
+// A path uses words 0,1 for the pixel jitter and two per bounce: words 0-7 (bounces 0-2) are staged
+// as two planes of 16 bytes per item (plane p of item i at planes[p * cap + i]: the bounce-0 readers
+// take consecutive items, so their loads are dense); later draws re-derive the block (WfRng).
+// Words 0,1 are only ever used for the pixel jitter, so their slots hold the jittered screen position
+// (primary_screen) instead: the refill of the bounce-0 trace then needs no item decoding (five integer
+// divisions) at all.  Items outside the image carry WF_ITEM_INVALID there.
+// ---------------------------------------------------------------------------
+#define WF_ITEM_INVALID 0x7fc0deadu   // a NaN pattern no arithmetic produces
+__global__ __launch_bounds__(256) void k_wf_rng(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
+                                                uint4* __restrict__ rng_planes) {
+    uint32_t rel = blockIdx.x * 256u + threadIdx.x;
+    if (rel >= W.n_items) return;
+    ItemRef it = decode_item(W.P, tile_offsets, W.item_base + rel);
+    if (!it.valid) {
+        rng_planes[rel] = make_uint4(WF_ITEM_INVALID, WF_ITEM_INVALID, 0u, 0u);
+        return;
+    }
+    uint32_t w[16];
+    pt_chacha12_block((uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples, 0u, w);
+    float sx, sy;
+    primary_screen(S, it.x, it.y, W.P.width, W.P.height, wf_rng_float(w[0]), wf_rng_float(w[1]), sx, sy);
+    rng_planes[rel] = make_uint4(__float_as_uint(sx), __float_as_uint(sy), w[2], w[3]);
+    rng_planes[(size_t)W.cap + rel] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-// Sequential draws of one path inside one kernel invocation: rng.gen::<f32>() number idx, idx + 1, ...
-// The ChaCha block holding idx is derived from the seed on first use and kept in registers.
+// rng.gen::<f32>() number idx of the path that started as work item `item` of the chunk: words 0-7 come
+// from the staged planes, later ones from the block re-derived on first use (kept in `fb`).
+#define WF_RNG_STAGED 8u
 struct WfRng {
-    uint64_t seed;
     uint32_t block;      // index of the block held in w (0xffffffff = none)
     uint32_t w[16];
 };
-PT_D void wf_rng_init(WfRng& r, uint32_t seed_lo, uint32_t seed_hi) {
-    r.seed = ((uint64_t)seed_hi << 32) | seed_lo;
-    r.block = 0xffffffffu;
+PT_D uint32_t wf_rng_staged(const uint4* __restrict__ planes, uint32_t cap, uint32_t item, uint32_t idx) {
+    const uint32_t* p = (const uint32_t*)(planes + (size_t)(idx >> 2) * cap + item);
+    return p[idx & 3u];
 }
-PT_D float wf_rng_draw(WfRng& r, uint32_t idx) {
-    if ((idx >> 4) != r.block) {
-        r.block = idx >> 4;
-        pt_chacha12_block(r.seed, r.block, r.w);
+PT_D float wf_rng_draw(WfRng& fb, const WfParams& W, const uint32_t* __restrict__ tile_offsets,
+                       const uint4* __restrict__ planes, uint32_t item, uint32_t idx) {
+    if (idx < WF_RNG_STAGED) return wf_rng_float(wf_rng_staged(planes, W.cap, item, idx));
+    if ((idx >> 4) != fb.block) {
+        ItemRef it = decode_item(W.P, tile_offsets, W.item_base + item);
+        fb.block = idx >> 4;
+        pt_chacha12_block((uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples, fb.block, fb.w);
     }
-    uint32_t word = r.w[0];
+    uint32_t word = fb.w[0];
 #pragma unroll
-    for (int i = 1; i < 16; ++i) word = (idx & 15u) == (uint32_t)i ? r.w[i] : word;
-    return (float)(word >> 8) * (1.0f / 16777216.0f);
+    for (int i = 1; i < 16; ++i) word = (idx & 15u) == (uint32_t)i ? fb.w[i] : word;
+    return wf_rng_float(word);
 }
 
 // ---------------------------------------------------------------------------
@@ -434,18 +510,21 @@ template <bool ALPHA, bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W,
                                                          const uint32_t* __restrict__ tile_offsets,
                                                          float4* __restrict__ queue, uint4* __restrict__ hits,
+                                                         const uint4* __restrict__ rng_planes,
                                                          WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
-    __shared__ uint2 lds_stack[WF_LDS_STACK * WF_THREADS];
+    __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
+    __shared__ unsigned long long lds_top[WF_LDS_NODES];
+    wf_load_tree_top(S, lds_top);
     const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
     uint32_t* cursor = &ctr[W.bounce].trace_work;
     uint32_t ov_node[PT_KD_STACK - WF_LDS_STACK];
     float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
-    const TravStack st = {lds_stack + threadIdx.x, ov_node, ov_tmax};
+    const TravStack st = {(wf_lds_u64*)(lds_stack + threadIdx.x), ov_node, ov_tmax, (const wf_lds_u64*)lds_top};
     Trav T;
     RawHit best, kept;       // kept: the last surface of the alpha walk when every hit was skipped
     bool have_kept = false;
     float t_prev = -INFINITY;
-    uint32_t ord_prev = 0, idx = 0, seed_lo = 0, seed_hi = 0, draw = 0;
+    uint32_t ord_prev = 0, idx = 0, item = 0, draw = 0;
     bool active = false, exhausted = false;
     uint32_t lstate = WF_LANE_IDLE;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
@@ -465,9 +544,9 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
             if (COUNT) lc.shaded++;
             bool stop = opacity >= 1.f;
             if (!stop && opacity > 0.001f) {
-                WfRng rng;   // rare path (translucent surfaces only): block re-derived per draw
-                wf_rng_init(rng, seed_lo, seed_hi);
-                float r = wf_rng_draw(rng, draw++);
+                WfRng fb;    // (draws past the staged words re-derive the block, per draw: rare)
+                fb.block = 0xffffffffu;
+                float r = wf_rng_draw(fb, W, tile_offsets, rng_planes, item, draw++);
                 stop = r < opacity;
                 if (COUNT) lc.shadow_rays++;  // (re-used as the alpha-draw counter in this kernel)
             }
@@ -533,14 +612,10 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
                 f3 o, d;
                 bool valid_item;
                 if (PRIMARY) {
-                    ItemRef it = decode_item(W.P, tile_offsets, W.item_base + idx);
-                    valid_item = it.valid;
+                    const uint2 sc = *(const uint2*)(rng_planes + idx);  // jittered screen position (k_wf_rng)
+                    valid_item = sc.x != WF_ITEM_INVALID;
                     o = d = mk3(0.f, 0.f, 0.f);
-                    if (valid_item) {
-                        uint32_t blk[16];
-                        pt_chacha12_block((uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples, 0u, blk);
-                        item_primary_ray(S, W.P, it, blk[0], blk[1], o, d);
-                    }
+                    if (valid_item) primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
                 } else {
                     const float4* q = queue + (size_t)idx * 4;
                     float4 q0 = q[0], q1 = q[1], q3 = q[3];
@@ -548,9 +623,8 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
                     d = mk3(q0.w, q1.x, q1.y);
                     valid_item = __float_as_uint(q3.z) != 0xffffffffu;
                     if (ALPHA) {
-                        seed_lo = __float_as_uint(q3.x);
+                        item = __float_as_uint(q3.x);
                         draw = __float_as_uint(q3.y) & 0xffffu;
-                        seed_hi = __float_as_uint(q3.w);
                     }
                 }
                 if (COUNT && valid_item) lc.segments++;
@@ -632,6 +706,7 @@ template <bool ALPHA, bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfParams W,
                                                   const uint32_t* __restrict__ tile_offsets,
                                                   const float4* __restrict__ queue_in, const uint4* __restrict__ hits,
+                                                  const uint4* __restrict__ rng_planes,
                                                   float4* __restrict__ queue_out, float4* __restrict__ shadow_q,
                                                   float4* __restrict__ contrib, float* __restrict__ staging,
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
@@ -646,7 +721,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
     uint32_t i = base + threadIdx.x;
     bool live = i < n;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), color = mk3(0, 0, 0);
-    uint32_t seed_lo = 0, seed_hi = 0, draw = 0, out_slot = 0;
+    uint32_t item = i, draw = 0, out_slot = 0;
     RawHit h;
     bool hit = false;
     WfRng rng;
@@ -656,13 +731,8 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         if (!it.valid) {
             live = false;
         } else {
-            uint64_t seed = (uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples;
-            wf_rng_init(rng, (uint32_t)seed, (uint32_t)(seed >> 32));
-            seed_lo = (uint32_t)seed;
-            seed_hi = (uint32_t)(seed >> 32);
-            rng.block = 0;
-            pt_chacha12_block(seed, 0u, rng.w);
-            item_primary_ray(S, W.P, it, rng.w[0], rng.w[1], o, d);
+            const uint2 sc = *(const uint2*)(rng_planes + i);  // jittered screen position (k_wf_rng)
+            primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
             thr = mk3(1.f, 1.f, 1.f);
             color = mk3(0.f, 0.f, 0.f);
             draw = 2;
@@ -678,10 +748,9 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         d = mk3(q0.w, q1.x, q1.y);
         thr = mk3(q1.z, q1.w, q2.x);
         color = mk3(q2.y, q2.z, q2.w);
-        seed_lo = __float_as_uint(q3.x);
+        item = __float_as_uint(q3.x);
         draw = __float_as_uint(q3.y) & 0xffffu;
         out_slot = __float_as_uint(q3.z);
-        seed_hi = __float_as_uint(q3.w);
         hit = unpack_hit(hits[i], h);
         if (out_slot == 0xffffffffu) live = false;  // item outside the image (k_wf_generate)
     }
@@ -709,11 +778,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         color = color + mul_ew(thr, ms.emissive);
         to_shadow = true;
         bool ended = false;
-        if (!PRIMARY) wf_rng_init(rng, seed_lo, seed_hi);
         if (bounce < bounces) {
             next_o = surf.pos + surf.normal * 0.00001f;
-            float r1 = wf_rng_draw(rng, draw++);
-            float r2 = wf_rng_draw(rng, draw++);
+            float r1 = wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++);
+            float r2 = wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++);
             next_d = ct_sample(brdf, normal, view, r1, r2);
             f3 wgt = ct_eval_indirect(brdf, normal, view, next_d) / 1.0f;
             next_thr = mul_ew(thr, wgt);
@@ -722,7 +790,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         if (!ended && bounce > 3) {
             float p = max_rs(max_rs(next_thr.x, next_thr.y), next_thr.z);
             next_thr = next_thr * (1.f / p);
-            if (wf_rng_draw(rng, draw++) > p) ended = true;
+            if (wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++) > p) ended = true;
         }
         survive = !ended && bounce + 1 <= bounces;
     }
@@ -753,8 +821,8 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         q[0] = make_float4(next_o.x, next_o.y, next_o.z, next_d.x);
         q[1] = make_float4(next_d.y, next_d.z, next_thr.x, next_thr.y);
         q[2] = make_float4(next_thr.z, color.x, color.y, color.z);  // colour is patched by k_wf_shadow
-        q[3] = make_float4(__uint_as_float(seed_lo), __uint_as_float((draw & 0xffffu) | ((bounce + 1) << 16)),
-                           __uint_as_float(out_slot), __uint_as_float(seed_hi));
+        q[3] = make_float4(__uint_as_float(item), __uint_as_float((draw & 0xffffu) | ((bounce + 1) << 16)),
+                           __uint_as_float(out_slot), 0.f);
     }
     if (to_shadow) {
         float4* sq = shadow_q + (size_t)sh_idx * 4;
@@ -786,12 +854,14 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
                                                           const float4* __restrict__ contrib,
                                                           float4* __restrict__ queue_next, float* __restrict__ staging,
                                                           WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
-    __shared__ uint2 lds_stack[WF_LDS_STACK * WF_THREADS];
+    __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
+    __shared__ unsigned long long lds_top[WF_LDS_NODES];
+    wf_load_tree_top(S, lds_top);
     const uint32_t n = ctr[W.bounce].shadow_count;
     uint32_t* cursor = &ctr[W.bounce].shadow_work;
     uint32_t ov_node[PT_KD_STACK - WF_LDS_STACK];
     float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
-    const TravStack st = {lds_stack + threadIdx.x, ov_node, ov_tmax};
+    const TravStack st = {(wf_lds_u64*)(lds_stack + threadIdx.x), ov_node, ov_tmax, (const wf_lds_u64*)lds_top};
     Trav T;
     // per-lane job state
     uint32_t idx = 0, li = 0, out_slot = 0, next_idx = 0;
