@@ -246,7 +246,7 @@ typedef struct pt_timing {
 typedef struct pt_counters {
     uint64_t samples;         /* path samples started                  */
     uint64_t segments;        /* closest-hit ray casts (R_seg)         */
-    uint64_t shadow_rays;     /* shadow ray casts (R_sh)               */
+    uint64_t shadow_rays;     /* get_light_info evaluations (R_sh)     */
     uint64_t nodes_visited;   /* KD nodes touched (V)                  */
     uint64_t tris_tested;     /* primitive tests (T)                   */
     uint64_t shaded_hits;     /* material fetches (H)                  */
@@ -256,6 +256,8 @@ typedef struct pt_counters {
     uint64_t casts_over_1k_nodes;
     uint64_t trace_nodes;          /* share of nodes_visited / tris_tested spent in  */
     uint64_t trace_tris;           /* closest-hit casts (the rest: shadow casts)      */
+    uint64_t shadow_skipped;       /* of shadow_rays: not cast, because the light's BRDF term is exactly 0
+                                    * and the visibility cannot change the colour                     */
 } pt_counters;
 
 int pt_get_timing(const pt_scene* scene, pt_timing* out);

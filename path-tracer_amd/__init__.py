@@ -105,7 +105,8 @@ class Timing(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "shadow_rays", "nodes_visited",
                                           "tris_tested", "shaded_hits", "rng_draws", "restarts",
-                                          "max_nodes_per_cast", "casts_over_1k_nodes", "trace_nodes", "trace_tris")]
+                                          "max_nodes_per_cast", "casts_over_1k_nodes", "trace_nodes", "trace_tris",
+                                          "shadow_skipped")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -35,7 +35,7 @@ struct DevLight {
     int32_t kind;
     float vec[3];
     float color[3];
-    float _pad;
+    uint32_t tame;   // 1: every |colour component| < 1e30 (so colour / (4 pi d^2) stays finite for d > 1e-3)
 };
 
 struct DevScene {
@@ -77,6 +77,6 @@ struct RenderParams {
 // Work counters (PT_FLAG_COUNTERS variant only).
 struct DevCounters {
     unsigned long long samples, segments, shadow_rays, nodes_visited, tris_tested, shaded_hits, rng_draws,
-        restarts, max_nodes_per_cast, casts_over_1k_nodes, trace_nodes, trace_tris;
+        restarts, max_nodes_per_cast, casts_over_1k_nodes, trace_nodes, trace_tris, shadow_skipped;
     unsigned long long stamps[8];  // diagnostic builds (-DWF_STAMPS) only
 };

@@ -657,7 +657,9 @@ void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
         lights[i].kind = d.lights[i].kind;
         memcpy(lights[i].vec, d.lights[i].vec, 12);
         memcpy(lights[i].color, d.lights[i].color, 12);
-        lights[i]._pad = 0.f;
+        lights[i].tame = 1u;
+        for (int k = 0; k < 3; ++k)
+            if (!(fabsf(d.lights[i].color[k]) < 1e30f)) lights[i].tame = 0u;  // also catches NaN
     }
 
     // ---- device node layout.  The builder emits DFS order (below child = next node); on the GPU the
@@ -1081,7 +1083,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         HIP_CHECK(hipMemcpy(&c, s.counter_buf.p, sizeof c, hipMemcpyDeviceToHost));
         s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
                                  c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes,
-                                 c.trace_nodes, c.trace_tris};
+                                 c.trace_nodes, c.trace_tris, c.shadow_skipped};
         if (getenv("PT_DEBUG_STAMPS"))
             fprintf(stderr, "[pt] trace stamps: refill %llu walk %llu leaf %llu complete %llu cycles | walk lanes/step %.1f (%llu steps) | leaf lanes/run %.1f (%llu runs)\n",
                     c.stamps[0], c.stamps[1], c.stamps[2], c.stamps[3], c.stamps[5] ? (double)c.stamps[4] / c.stamps[5] : 0.0,

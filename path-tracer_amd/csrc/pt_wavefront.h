@@ -160,6 +160,9 @@ PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursor, uint32_t n, bool need,
 #ifndef WF_MIN_WAVES
 #define WF_MIN_WAVES 1   // minimum waves per SIMD the trace/shadow kernels are compiled for
 #endif
+#ifndef WF_PRIMARY_WAVES
+#define WF_PRIMARY_WAVES 5   // the bounce-0 trace is held to the register budget of the other bounces
+#endif
 
 struct Trav {
     f3 o, d, inv;
@@ -507,7 +510,7 @@ PT_D float wf_rng_draw(WfRng& fb, const WfParams& W, const uint32_t* __restrict_
 // camera ray is derived in place (decode + ChaCha block 0), which removes k_wf_generate's 64 B/item
 // write and this kernel's 48 B/item read.
 template <bool ALPHA, bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W,
+__global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES : WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W,
                                                          const uint32_t* __restrict__ tile_offsets,
                                                          float4* __restrict__ queue, uint4* __restrict__ hits,
                                                          const uint4* __restrict__ rng_planes,
@@ -648,6 +651,8 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
         // ---- phase A: walk
         for (uint32_t k = 0; k < W.walk_steps; ++k) {
             const bool walking = lstate == WF_LANE_WALK;
+            // (kept to a compare + branch on vcc: a popcount threshold here - leave once only a few lanes
+            // still walk - put a VALU->SALU dependency on the critical path of every step and cost 18 %)
             if (!wf_any(walking)) break;
 #ifdef WF_STAMPS
             st_walk_lanes += __popcll(__ballot(walking));
@@ -673,15 +678,14 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
     }
 #ifdef WF_STAMPS
     if (COUNT && (threadIdx.x & 63u) == 0) {
-        unsigned long long* slot = &gctr->samples;  // DevCounters is an array of u64
-        atomicAdd(slot + 12, st_refill);
-        atomicAdd(slot + 13, st_walk);
-        atomicAdd(slot + 14, st_leaf);
-        atomicAdd(slot + 15, st_done);
-        atomicAdd(slot + 16, st_walk_lanes);
-        atomicAdd(slot + 17, st_walk_steps);
-        atomicAdd(slot + 18, st_leaf_lanes);
-        atomicAdd(slot + 19, st_leaf_runs);
+        atomicAdd(&gctr->stamps[0], st_refill);
+        atomicAdd(&gctr->stamps[1], st_walk);
+        atomicAdd(&gctr->stamps[2], st_leaf);
+        atomicAdd(&gctr->stamps[3], st_done);
+        atomicAdd(&gctr->stamps[4], st_walk_lanes);
+        atomicAdd(&gctr->stamps[5], st_walk_steps);
+        atomicAdd(&gctr->stamps[6], st_leaf_lanes);
+        atomicAdd(&gctr->stamps[7], st_leaf_runs);
     }
 #endif
     if (COUNT) {
@@ -694,6 +698,15 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace(DevScene 
         if (ALPHA) atomicAdd(&gctr->shaded_hits, (unsigned long long)lc.shaded);
         if (ALPHA) atomicAdd(&gctr->rng_draws, (unsigned long long)lc.shadow_rays);
     }
+}
+
+// A light whose term (thr ⊙ eval_direct) is exactly (0,0,0) - it lies below the shading horizon and the
+// surface is not emissive - adds 0 ⊙ radiance to the colour (mod.rs:255-261), i.e. nothing, whatever
+// the shadow ray finds, as long as the radiance is finite: colour finite and, for a point light, the
+// surface not within 1e-3 of it (colour / (4 pi d^2) < 1e30 / 1.2e-5).  Those shadow rays are not cast.
+PT_D bool wf_light_is_moot(const DevLight& L, f3 term, f3 surface_pos) {
+    if (!(term.x == 0.f && term.y == 0.f && term.z == 0.f) || !L.tame) return false;
+    return L.kind != PT_LIGHT_POINT || mag3(surface_pos - ld3(L.vec)) > 1e-3f;
 }
 
 // ---------------------------------------------------------------------------
@@ -711,7 +724,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
                                                   float4* __restrict__ contrib, float* __restrict__ staging,
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
-    uint32_t n_draws = 0, n_new = 0;
+    uint32_t n_draws = 0, n_new = 0, n_moot = 0;
     __shared__ uint32_t sh_cnt[2][WF_SHADE_THREADS / 64];
     __shared__ uint32_t sh_base[2];
     const uint32_t wave = threadIdx.x >> 6;
@@ -756,6 +769,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
     }
     const uint32_t bounce = W.bounce, bounces = W.P.bounces;
     bool to_shadow = false, survive = false;
+    f3 term0 = mk3(0.f, 0.f, 0.f);
     Surface surf;
     f3 next_o = o, next_d = d, next_thr = thr;
     if (live && !hit) {  // background (mod.rs:184-186): the path ends here
@@ -776,7 +790,16 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         view = -1.f * d;
         ct_init(brdf, ms);
         color = color + mul_ew(thr, ms.emissive);
-        to_shadow = true;
+        // (thr ⊙ eval_direct) per light; the visibility factor is applied by k_wf_shadow.  The first
+        // light's term stays in registers, the others are recomputed when the record is written.
+        for (uint32_t li = 0; li < S.n_lights; ++li) {
+            const DevLight& L = S.lights[li];
+            f3 ldir = L.kind == PT_LIGHT_POINT ? normalize3(surf.pos - ld3(L.vec)) : ld3(L.vec);
+            f3 c = mul_ew(thr, ct_eval_direct(brdf, normal, view, -1.f * ldir));
+            if (li == 0) term0 = c;
+            if (!wf_light_is_moot(L, c, surf.pos)) to_shadow = true;
+        }
+        if (COUNT && !to_shadow) n_moot += S.n_lights;
         bool ended = false;
         if (bounce < bounces) {
             next_o = surf.pos + surf.normal * 0.00001f;
@@ -830,18 +853,27 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfPar
         sq[1] = make_float4(surf.normal.y, surf.normal.z, surf.uv.x, surf.uv.y);
         sq[2] = make_float4(color.x, color.y, color.z, __uint_as_float(survive ? next_idx : 0xffffffffu));
         sq[3] = make_float4(__uint_as_float(out_slot), __uint_as_float(surf.sphere ? WF_FLAG_SPHERE : 0u), 0.f, 0.f);
-        // (thr ⊙ eval_direct) per light; the visibility factor is applied by k_wf_shadow
-        for (uint32_t li = 0; li < S.n_lights; ++li) {
+        contrib[sh_idx] = make_float4(term0.x, term0.y, term0.z, 0.f);
+        for (uint32_t li = 1; li < S.n_lights; ++li) {
             const DevLight& L = S.lights[li];
             f3 ldir = L.kind == PT_LIGHT_POINT ? normalize3(surf.pos - ld3(L.vec)) : ld3(L.vec);
             f3 c = mul_ew(thr, ct_eval_direct(brdf, normal, view, -1.f * ldir));
             contrib[(size_t)li * W.cap + sh_idx] = make_float4(c.x, c.y, c.z, 0.f);
         }
+    } else if (live && hit && !survive) {  // no light can contribute and the path ends: the sample is complete
+        float* out = staging + (size_t)out_slot * 3;
+        out[0] = color.x;
+        out[1] = color.y;
+        out[2] = color.z;
     }
     if (COUNT && live) n_draws += PRIMARY ? draw : draw - (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu);
     }  // grid-stride loop
     if (COUNT && n_draws) atomicAdd(&gctr->rng_draws, (unsigned long long)n_draws);
     if (COUNT && n_new) atomicAdd(&gctr->samples, (unsigned long long)n_new);
+    if (COUNT && n_moot) {
+        atomicAdd(&gctr->shadow_rays, (unsigned long long)n_moot);
+        atomicAdd(&gctr->shadow_skipped, (unsigned long long)n_moot);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -890,6 +922,17 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
     auto begin_light = [&]() -> bool {
         while (li < S.n_lights) {
             const DevLight& L = S.lights[li];
+            if (S.n_lights > 1) {  // (a single light was already filtered by k_wf_shade)
+                float4 c = contrib[(size_t)li * W.cap + idx];
+                if (wf_light_is_moot(L, mk3(c.x, c.y, c.z), pos)) {
+                    if (COUNT) {
+                        lc.shadow_rays++;
+                        lc.shaded++;   // (re-used as the skipped-cast counter in this kernel)
+                    }
+                    ++li;
+                    continue;
+                }
+            }
             point = L.kind == PT_LIGHT_POINT;
             f3 direction;
             rad = ld3(L.color);
@@ -1013,6 +1056,8 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
         // ---- phase A: walk
         for (uint32_t k = 0; k < W.walk_steps; ++k) {
             const bool walking = lstate == WF_LANE_WALK;
+            // (kept to a compare + branch on vcc: a popcount threshold here - leave once only a few lanes
+            // still walk - put a VALU->SALU dependency on the critical path of every step and cost 18 %)
             if (!wf_any(walking)) break;
             if (walking) lstate = trav_step<COUNT>(S, T, st, ALPHA ? best.key : limit, lc);
         }
@@ -1055,6 +1100,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
     }
     if (COUNT) {
         atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);
+        atomicAdd(&gctr->shadow_skipped, (unsigned long long)lc.shaded);
         atomicAdd(&gctr->nodes_visited, (unsigned long long)lc.nodes);
         atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
         atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
