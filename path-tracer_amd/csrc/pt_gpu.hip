@@ -1002,7 +1002,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     // shade(b) reads the colours shadow(b-1) patched and refills the shadow queue it consumed
                     if (st_shadow != st_main && b > 0) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
                     stage_begin(2);
-                    PT_LAUNCH_ACP(k_wf_shade, (uint32_t)(s.n_cu * 4), WF_SHADE_THREADS, s.dev, W, d_tiles, (const float4*)q_in,
+                    PT_LAUNCH_ACP(k_wf_shade, (uint32_t)(s.n_cu * 4 * (1024 / WF_SHADE_THREADS)), WF_SHADE_THREADS, s.dev, W, d_tiles, (const float4*)q_in,
                                   (const uint4*)pipe.hits.p, (const uint4*)pipe.rng.p, q_out, (float4*)pipe.shadow.p,
                                   (float4*)pipe.contrib.p,
                                   (float*)s.staging_buf.p, wctr, gctr);

@@ -191,6 +191,7 @@ struct TravStack {
 #define WF_LDS_NODES 1024
 #endif
 PT_D void wf_load_tree_top(const DevScene& S, unsigned long long* lds_top) {
+    if (WF_LDS_NODES == 0) return;
     const uint32_t n = S.n_node_slots < (uint32_t)WF_LDS_NODES ? S.n_node_slots : (uint32_t)WF_LDS_NODES;
     for (uint32_t i = threadIdx.x; i < n; i += WF_THREADS) {
         uint2 g = S.kd_nodes[i];
@@ -286,12 +287,21 @@ PT_D bool trav_pop(Trav& T, const TravStack& st, float limit) {
 // and took ~4400 cycles per wave-step whatever the scene size (profiles/r01_f_trace_stamps.txt).
 template <bool COUNT>
 PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float limit, LocalCtr& lc) {
-    // LDS read first and unconditional (clamped index): the global fetch of the deeper lanes must not
-    // wait behind it, nor the other way round
+#if WF_LDS_NODES > 0
+    // Deep lanes fetch from memory, all lanes read the (clamped) LDS slot, and the two results are merged
+    // with explicit selects: they must sit in different registers, or the compiler serialises the two
+    // fetches (one waits for the other's destination registers).
+    const unsigned long long deep = __builtin_amdgcn_uicmp(T.node, (uint32_t)WF_LDS_NODES, 35);  // UGE
+    uint2 g = make_uint2(0u, 0u);
+    if (T.node >= (uint32_t)WF_LDS_NODES) g = S.kd_nodes[T.node];
     const uint32_t top_slot = T.node < (uint32_t)WF_LDS_NODES ? T.node : (uint32_t)WF_LDS_NODES - 1u;
     const unsigned long long e = st.top[top_slot];
-    uint2 nd = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
-    if (T.node >= (uint32_t)WF_LDS_NODES) nd = S.kd_nodes[T.node];
+    uint2 nd;
+    nd.x = __float_as_uint(wf_select(deep, __uint_as_float(g.x), __uint_as_float((uint32_t)e)));
+    nd.y = __float_as_uint(wf_select(deep, __uint_as_float(g.y), __uint_as_float((uint32_t)(e >> 32))));
+#else
+    const uint2 nd = S.kd_nodes[T.node];
+#endif
     if (COUNT) lc.nodes++;
     const uint32_t axis = nd.y & 3u;
     if (axis != 3u) {
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
                                                          const uint4* __restrict__ rng_planes,
                                                          WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
-    __shared__ unsigned long long lds_top[WF_LDS_NODES];
+    __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
     wf_load_tree_top(S, lds_top);
     const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
     uint32_t* cursor = &ctr[W.bounce].trace_work;
@@ -713,10 +723,17 @@ PT_D bool wf_light_is_moot(const DevLight& L, f3 term, f3 surface_pos) {
 // shade: compute_radiance without the light visibility (mod.rs:230-278)
 // ---------------------------------------------------------------------------
 #ifndef WF_SHADE_THREADS
-#define WF_SHADE_THREADS 1024  // 16 waves: one compaction atomic per 1024 entries; 128 VGPRs (512: 166, 256: 214)
+// Workgroup = compaction unit (one atomic per queue and workgroup) and barrier domain.  MI355X, config 3,
+// shade stage per 64 spp: 1024 threads 8.45 ms (one workgroup per CU: its three barriers stall the whole
+// CU on the slowest wave), 512: 7.33, 256: 6.9, 128: 10.2 (the queue counters saturate: ~88 returning
+// atomics per microsecond and word).  Register budget WF_SHADE_WAVES in every case.
+#define WF_SHADE_THREADS 256
 #endif
 template <bool ALPHA, bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(WF_SHADE_THREADS) void k_wf_shade(DevScene S, WfParams W,
+#ifndef WF_SHADE_WAVES
+#define WF_SHADE_WAVES 4      // waves per SIMD the kernel is compiled for (register budget 512 / 4)
+#endif
+__global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(DevScene S, WfParams W,
                                                   const uint32_t* __restrict__ tile_offsets,
                                                   const float4* __restrict__ queue_in, const uint4* __restrict__ hits,
                                                   const uint4* __restrict__ rng_planes,
@@ -887,7 +904,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
                                                           float4* __restrict__ queue_next, float* __restrict__ staging,
                                                           WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
-    __shared__ unsigned long long lds_top[WF_LDS_NODES];
+    __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
     wf_load_tree_top(S, lds_top);
     const uint32_t n = ctr[W.bounce].shadow_count;
     uint32_t* cursor = &ctr[W.bounce].shadow_work;
