@@ -244,7 +244,9 @@ PT_D void stack_get(const TravStack& st, int sp, uint32_t& node, float& tmax) {
 PT_D bool trav_start(const DevScene& S, Trav& T, f3 o, f3 d, float t_start) {
     T.o = o;
     T.d = d;
-    T.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // v_rcp_f32 (1 ulp) instead of three IEEE divisions (~10 instructions each): the reciprocals only
+    // place the split planes along the ray, and every plane test carries a 1e-5 relative slack
+    T.inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     float dlen = mag3(d);
     T.key_scale = dlen < 1.0f ? dlen : 1.0f;
     T.dneg = (d.x <= 0.f ? 1u : 0u) | (d.y <= 0.f ? 2u : 0u) | (d.z <= 0.f ? 4u : 0u);
@@ -334,6 +336,8 @@ PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float l
     return trav_pop(T, st, limit) ? WF_LANE_WALK : WF_LANE_DONE;  // empty leaf: straight on to the next segment
 }
 
+// (The 48-byte leaf records are read with plain loads: a primitive is referenced from ~7 leaves, and
+// marking these loads non-temporal cost 19 % of the trace stage.)
 // Closest-hit candidate update for one leaf (same acceptance rule as next_hit()).
 template <bool COUNT>
 PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_prev, uint32_t ord_prev, RawHit& best,
