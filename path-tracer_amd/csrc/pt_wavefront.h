@@ -108,11 +108,19 @@ PT_D uint32_t wf_reserve(uint32_t* counter, bool want) {
 // saturates at ~88 per microsecond on MI355X (MI355X_MICROARCH.md, "dequeue"), which a
 // per-refill atomic hits at a few hundred Mrays/s; so a wavefront reserves WF_CHUNK entries at a
 // time and hands them to its idle lanes from wave-uniform registers (ballot + mbcnt prefix).
+// The reservation shrinks with the queue (>= ~16 reservations per wavefront, 64 ... 512 entries): with 512 a
+// launch of a few million rays gave most waves one or two reservations of 8 rays per lane, and every
+// persistent launch had a ~1 ms floor (drain of the last reservations) however short its queue.
 #define WF_CHUNK 512u
 struct WaveFetch {
     uint32_t cur, end;
     bool done;
+    uint32_t chunk;
 };
+PT_D uint32_t wf_chunk_for(uint32_t n) {
+    const uint32_t per_wave = n / (gridDim.x * (blockDim.x / 64u) * 16u);
+    return per_wave >= WF_CHUNK ? WF_CHUNK : per_wave >= 256u ? 256u : per_wave >= 128u ? 128u : 64u;
+}
 
 PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursor, uint32_t n, bool need, bool& got, bool& exhausted) {
     got = false;
@@ -121,13 +129,13 @@ PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursor, uint32_t n, bool need,
     if (wf.cur >= wf.end && !wf.done) {
         int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
-        if ((int)__lane_id() == leader) base = atomicAdd(cursor, WF_CHUNK);
+        if ((int)__lane_id() == leader) base = atomicAdd(cursor, wf.chunk);
         base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
         if (base >= n) {
             wf.done = true;
         } else {
             wf.cur = base;
-            wf.end = base + WF_CHUNK < n ? base + WF_CHUNK : n;
+            wf.end = base + wf.chunk < n ? base + wf.chunk : n;
         }
     }
     uint32_t w = 0;
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
     uint32_t lstate = WF_LANE_IDLE;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     uint32_t cast_nodes0 = 0;
-    WaveFetch wf = {0u, 0u, false};
+    WaveFetch wf = {0u, 0u, false, wf_chunk_for(n)};
 
     // the current cast has no further segment: best = next entry of the sorted hit list (or none)
     // (called from ONE place per loop iteration to keep the kernel's register footprint small)
@@ -930,7 +938,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
     bool active = false, exhausted = false, need_begin = false;
     uint32_t lstate = WF_LANE_IDLE;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
-    WaveFetch wf = {0u, 0u, false};
+    WaveFetch wf = {0u, 0u, false, wf_chunk_for(n)};
 
     auto add_light = [&]() {  // visibility known: add the light (mod.rs:251-261)
         if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) {
