@@ -271,6 +271,10 @@ class HostScene:
     def n_prims(self):
         return int(host_lib().pth_prim_count(self.desc))
 
+    @property
+    def n_lights(self):
+        return int(self.desc.contents.n_lights)
+
     def close(self):
         if self.handle:
             host_lib().pth_scene_free(self.handle)

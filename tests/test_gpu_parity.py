@@ -364,3 +364,90 @@ def test_copy_bandwidth_yardstick(pta):
     assert 1000.0 < gbs < 8000.0, gbs
     with pytest.raises(pta.PtError):
         pta.measure_copy_bandwidth(0, 8, 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes.  The oracle cannot render these frames in test time, so the checks are
+# (a) size-independent properties of the path (any partition of the pixels / of the samples gives the
+# same bits; event counters obey the path's identities) and (b) the oracle on a bounded sample of rows
+# of the very same frame, which must equal the GPU's rows bit for bit.
+# ---------------------------------------------------------------------------------------------
+def _oracle_rows_equal(pta, oracle, scene, prof, gpu_acc, gpu_rgb, rows):
+    osc = oracle.OracleScene(scene.desc, oracle.PTO_BVH)
+    for y in rows:
+        begin, end = y * prof.width, (y + 1) * prof.width
+        o_rgb, o_acc, _ = osc.render(prof, begin, end)
+        assert np.array_equal(bits(o_acc), bits(gpu_acc[begin:end])), f"row {y}: accumulation differs"
+        assert np.array_equal(o_rgb, gpu_rgb[begin:end]), f"row {y}: image differs"
+
+
+@pytest.fixture(scope="module")
+def ps5_scene(pta):
+    scene = pta.HostScene.generate_ps5(500000, seed=0)
+    return scene, pta.GpuScene(scene)
+
+
+def test_config3_full_size(pta, oracle, ps5_scene):
+    """BASELINE config 3: PS5 stand-in (499 392 triangles), 1920x1080, 128 spp, 5 bounces, FILMIC."""
+    scene, g = ps5_scene
+    prof = pta.Profile.make(1920, 1080, 128, 5, "FILMIC")
+    rgb, acc = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS))
+    c = g.counters().as_dict()
+    n = prof.width * prof.height * prof.samples
+    assert c["samples"] == n and c["segments"] >= n                 # every sample casts its camera ray
+    assert c["shadow_rays"] == c["shaded_hits"] * scene.n_lights  # one get_light_info per light per hit
+    assert c["segments"] - n <= c["shaded_hits"] <= c["segments"]    # a segment beyond the first needs a shaded hit
+    assert c["rng_draws"] >= 2 * n and c["shadow_skipped"] <= c["shadow_rays"]
+    assert np.isfinite(acc).all() and rgb.max() > 0
+    # (b) oracle rows: top, two through the model, bottom (ground plane)
+    _oracle_rows_equal(pta, oracle, scene, prof, acc, rgb, (0, 431, 540, 1079))
+    # (a) any partition of the samples: three batches of 48 / 48 / 32
+    rgb_b, acc_b = g.render(prof, pta.Opts.make(sample_batch=48))
+    assert np.array_equal(bits(acc_b), bits(acc)) and np.array_equal(rgb_b, rgb)
+    # (a) any partition of the pixels: 8 ranks of interleaved 32x32 tiles (BASELINE config 4's sharding)
+    seen = np.zeros(prof.width * prof.height, bool)
+    for rank in range(8):
+        opts = pta.Opts.make(shard_rank=rank, shard_count=8, tile_w=32, tile_h=32)
+        idx = pta.local_pixel_map(prof, opts)
+        r_rgb, r_acc = g.render(prof, opts)
+        assert np.array_equal(bits(r_acc), bits(acc[idx])) and np.array_equal(r_rgb, rgb[idx])
+        assert not seen[idx].any()
+        seen[idx] = True
+    assert seen.all()
+
+
+def test_config4_bounces_and_samples(pta, oracle, ps5_scene):
+    """BASELINE config 4's path length (8 bounces) on the same scene; 512 spp is the sum of four 128-sample
+    renders only through the seed formula, so the sample count is exercised with a prime (131) instead."""
+    scene, g = ps5_scene
+    prof = pta.Profile.make(1920, 1080, 131, 8, "FILMIC")
+    opts = pta.Opts.make(shard_rank=5, shard_count=8, tile_w=32, tile_h=32)   # one rank of the 8-GPU job
+    idx = pta.local_pixel_map(prof, opts)
+    rgb, acc = g.render(prof, opts)
+    osc = oracle.OracleScene(scene.desc, oracle.PTO_BVH)
+    for y in (300, 700):   # the rank's pixels of two rows, from the oracle's full rows
+        begin = y * prof.width
+        o_rgb, o_acc, _ = osc.render(prof, begin, begin + prof.width)
+        mine = np.nonzero((idx >= begin) & (idx < begin + prof.width))[0]
+        assert len(mine) > 0
+        assert np.array_equal(bits(o_acc[idx[mine] - begin]), bits(acc[mine]))
+        assert np.array_equal(o_rgb[idx[mine] - begin], rgb[mine])
+
+
+def test_config5_translucent_4k(pta, oracle):
+    """BASELINE config 5's ingredients at full resolution: 3840x2160, translucent shells (opacity factor +
+    checker opacity texture: alpha walk with RNG draws, ordered shadow attenuation), 8 bounces, ACES.  The
+    triangle count (1 M instead of 4 M) and the sample count (8 instead of 1024) are reduced for test time;
+    neither enters the arithmetic of a sample."""
+    scene = pta.HostScene.generate_ps5(1000000, seed=0, flags=1)
+    g = pta.GpuScene(scene)
+    assert g.info().has_translucent == 1
+    prof = pta.Profile.make(3840, 2160, 8, 8, "ACES")
+    rgb, acc = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS))
+    c = g.counters().as_dict()
+    assert c["samples"] == prof.width * prof.height * prof.samples and c["restarts"] > 0
+    _oracle_rows_equal(pta, oracle, scene, prof, acc, rgb, (700, 1080, 1500))
+    opts = pta.Opts.make(shard_rank=2, shard_count=8, tile_w=32, tile_h=32)
+    idx = pta.local_pixel_map(prof, opts)
+    r_rgb, r_acc = g.render(prof, opts)
+    assert np.array_equal(bits(r_acc), bits(acc[idx])) and np.array_equal(r_rgb, rgb[idx])
