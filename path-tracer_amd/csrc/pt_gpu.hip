@@ -525,9 +525,9 @@ struct pt_scene {
     // The queues of the chunk of work items in flight.  The shadow casts of bounce b run on a side stream
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
-        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng;
-        hipStream_t side = nullptr;
-        hipEvent_t ev_shade = nullptr, ev_shadow = nullptr;
+        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2];
+        hipStream_t side = nullptr, side_rng = nullptr;
+        hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr;
     };
     mutable WfPipe pipe;
     mutable int persist_blocks = 0, trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
@@ -538,9 +538,10 @@ struct pt_scene {
         (void)hipSetDevice(device);
         for (void* p : allocations) (void)hipFree(p);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {pipe.ev_shade, pipe.ev_shadow})
+        for (hipEvent_t e : {pipe.ev_shade, pipe.ev_shadow, pipe.ev_rng, pipe.ev_chunk})
             if (e) (void)hipEventDestroy(e);
         if (pipe.side) (void)hipStreamDestroy(pipe.side);
+        if (pipe.side_rng) (void)hipStreamDestroy(pipe.side_rng);
     }
     template <class T>
     const T* upload(const T* host, size_t count) {
@@ -819,7 +820,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     }();
     static const uint32_t wf_cap = [] {
         const char* e = getenv("PT_WF_CHUNK");
-        return (uint32_t)(e && *e ? atof(e) : 128.0 * 1024 * 1024);
+        // 320 Mi work items = 80 GiB of queues (256 B per item) of the 288 GB: a whole 1080p x 128 spp frame is
+        // ONE chunk (every extra chunk repeats the ~13 persistent launches and their drain phases: 60.9 ms
+        // against 63.0 ms for two chunks of 128 Mi)
+        return (uint32_t)(e && *e ? atof(e) : 320.0 * 1024 * 1024);
     }();
     static const bool wf_overlap = [] {    // shadow(b) on a side stream beside trace(b+1); PT_WF_OVERLAP=0 serialises
         const char* e = getenv("PT_WF_OVERLAP");
@@ -889,7 +893,18 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         w.shadow.ensure((size_t)cap * 64u);
         w.contrib.ensure((size_t)cap * 16u * std::max(1u, s.dev.n_lights));
         w.ctr.ensure(sizeof(WfCounters) * (p.bounces + 3));
-        w.rng.ensure((size_t)cap * 32u);   // words 0-7 of every item's ChaCha block, two 16-byte planes
+        // words 0-7 of every item's ChaCha block, two 16-byte planes; a second copy when the batch has several
+        // chunks, so that the next chunk's k_wf_rng can run underneath the current chunk's bounces
+        const bool multi_chunk = (uint64_t)cap < items_per_batch;
+        w.rng[0].ensure((size_t)cap * 32u);
+        if (multi_chunk && wf_overlap && !alpha) {
+            w.rng[1].ensure((size_t)cap * 32u);
+            if (!w.side_rng) {
+                HIP_CHECK(hipStreamCreateWithFlags(&w.side_rng, hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreateWithFlags(&w.ev_rng, hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&w.ev_chunk, hipEventDisableTiming));
+            }
+        }
         if (wf_overlap && !w.side) {
             HIP_CHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_shade, hipEventDisableTiming));
@@ -950,27 +965,55 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             const pt_scene::WfPipe& pipe = s.pipe;
             hipStream_t st_main = stream;
             hipStream_t st_shadow = wf_overlap ? pipe.side : st_main;
-            for (uint32_t base = 0; base < total_items; base += cap) {
+            // opaque scenes, several chunks: the RNG planes of chunk c+1 are produced on their own stream while
+            // chunk c runs its bounces (k_wf_rng is pure integer ALU work; the traversal kernels leave ~40 % of
+            // the issue slots idle and end in a drain phase)
+            const bool rng_ahead = !alpha && wf_overlap && total_items > cap && pipe.side_rng != nullptr;
+            uint32_t chunk_no = 0;
+            for (uint32_t base = 0; base < total_items; base += cap, ++chunk_no) {
                 WfParams W{};
                 W.P = P;
                 W.item_base = base;
                 W.n_items = std::min(cap, total_items - base);
                 W.cap = cap;
+                uint4* rng_planes = (uint4*)pipe.rng[rng_ahead ? (chunk_no & 1u) : 0u].p;
                 W.refill_min = std::max(1u, std::min(64u, wf_refill));
                 W.walk_steps = std::max(1u, wf_walk);
                 WfCounters* wctr = (WfCounters*)pipe.ctr.p;
                 HIP_CHECK(hipMemsetAsync(wctr, 0, sizeof(WfCounters) * (p.bounces + 3), st_main));
                 // bounce 0 of opaque scenes derives the camera rays in place (no generate kernel, no queue[0])
                 const bool fused_primary = !alpha;
-                stage_begin(0);
-                if (!fused_primary)
+                if (!fused_primary) {
+                    stage_begin(0);
                     hipLaunchKernelGGL(k_wf_generate, dim3((W.n_items + 255u) / 256u), dim3(256), 0, st_main, s.dev, W, d_tiles,
-                                       (float4*)pipe.queue[0].p, (uint4*)pipe.rng.p, wctr, gctr);
-                else
+                                       (float4*)pipe.queue[0].p, rng_planes, wctr, gctr);
+                    HIP_CHECK(hipGetLastError());
+                    stage_end();
+                } else if (!rng_ahead || chunk_no == 0) {
+                    stage_begin(0);
                     hipLaunchKernelGGL(k_wf_rng, dim3((W.n_items + 255u) / 256u), dim3(256), 0, st_main, s.dev, W, d_tiles,
-                                       (uint4*)pipe.rng.p);
-                HIP_CHECK(hipGetLastError());
-                stage_end();
+                                       rng_planes);
+                    HIP_CHECK(hipGetLastError());
+                    stage_end();
+                } else {
+                    HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_rng, 0));  // produced underneath the previous chunk
+                }
+                if (rng_ahead && base + cap < total_items) {
+                    // the other copy was last read by chunk c-1, which has completed on st_main by now
+                    WfParams Wn = W;
+                    Wn.item_base = base + cap;
+                    Wn.n_items = std::min(cap, total_items - Wn.item_base);
+                    HIP_CHECK(hipEventRecord(pipe.ev_chunk, st_main));
+                    HIP_CHECK(hipStreamWaitEvent(pipe.side_rng, pipe.ev_chunk, 0));
+                    stage_stream = pipe.side_rng;
+                    stage_begin(0);
+                    hipLaunchKernelGGL(k_wf_rng, dim3((Wn.n_items + 255u) / 256u), dim3(256), 0, pipe.side_rng, s.dev, Wn,
+                                       d_tiles, (uint4*)pipe.rng[(chunk_no + 1u) & 1u].p);
+                    HIP_CHECK(hipGetLastError());
+                    stage_end();
+                    stage_stream = st_main;
+                    HIP_CHECK(hipEventRecord(pipe.ev_rng, pipe.side_rng));
+                }
                 for (uint32_t b = 0; b <= p.bounces; ++b) {
                     W.bounce = b;
                     float4* q_in = (float4*)pipe.queue[b & 1].p;
@@ -996,14 +1039,14 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     } while (0)
                     stage_begin(1);
                     PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, 256, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
-                                  (const uint4*)pipe.rng.p, wctr, gctr);
+                                  (const uint4*)rng_planes, wctr, gctr);
                     stage_end();
                     ++launches;
                     // shade(b) reads the colours shadow(b-1) patched and refills the shadow queue it consumed
                     if (st_shadow != st_main && b > 0) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
                     stage_begin(2);
                     PT_LAUNCH_ACP(k_wf_shade, (uint32_t)(s.n_cu * 4 * (1024 / WF_SHADE_THREADS)), WF_SHADE_THREADS, s.dev, W, d_tiles, (const float4*)q_in,
-                                  (const uint4*)pipe.hits.p, (const uint4*)pipe.rng.p, q_out, (float4*)pipe.shadow.p,
+                                  (const uint4*)pipe.hits.p, (const uint4*)rng_planes, q_out, (float4*)pipe.shadow.p,
                                   (float4*)pipe.contrib.p,
                                   (float*)s.staging_buf.p, wctr, gctr);
                     stage_end();
