@@ -500,12 +500,23 @@ struct DeviceBuffer {
     void* p = nullptr;
     size_t bytes = 0;
     void ensure(size_t n) {
-        if (n <= bytes) return;
+        if (!try_ensure(n)) fail(PT_ERR_DEVICE, "hipMalloc of %zu bytes failed: out of device memory", n);
+    }
+    bool try_ensure(size_t n) {  // false (buffer released) when the device cannot provide n bytes
+        if (n <= bytes) return true;
+        release();
+        if (hipMalloc(&p, n) != hipSuccess) {
+            (void)hipGetLastError();  // clear the sticky error
+            p = nullptr;
+            return false;
+        }
+        bytes = n;
+        return true;
+    }
+    void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
-        HIP_CHECK(hipMalloc(&p, n));
-        bytes = n;
     }
     ~DeviceBuffer() {
         if (p) (void)hipFree(p);
@@ -887,18 +898,28 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             }
         }
         pt_scene::WfPipe& w = s.pipe;
-        w.queue[0].ensure((size_t)cap * 64u);
-        w.queue[1].ensure((size_t)cap * 64u);
-        w.hits.ensure((size_t)cap * 16u);
-        w.shadow.ensure((size_t)cap * 64u);
-        w.contrib.ensure((size_t)cap * 16u * std::max(1u, s.dev.n_lights));
         w.ctr.ensure(sizeof(WfCounters) * (p.bounces + 3));
-        // words 0-7 of every item's ChaCha block, two 16-byte planes; a second copy when the batch has several
-        // chunks, so that the next chunk's k_wf_rng can run underneath the current chunk's bounces
-        const bool multi_chunk = (uint64_t)cap < items_per_batch;
-        w.rng[0].ensure((size_t)cap * 32u);
+        // The queues: 256 B per work item (+32 B for the second copy of the RNG planes of multi-chunk batches:
+        // words 0-7 of every item's ChaCha block, two 16-byte planes, so that the next chunk's k_wf_rng can
+        // run underneath the current chunk's bounces).  A device that cannot provide them (shared GPU) gets
+        // half-size chunks, and so on, down to 1 Mi items.
+        bool multi_chunk = false;
+        while (true) {
+            multi_chunk = (uint64_t)cap < items_per_batch;
+            const size_t lights = std::max(1u, s.dev.n_lights);
+            bool ok = w.queue[0].try_ensure((size_t)cap * 64u) && w.queue[1].try_ensure((size_t)cap * 64u) &&
+                      w.hits.try_ensure((size_t)cap * 16u) && w.shadow.try_ensure((size_t)cap * 64u) &&
+                      w.contrib.try_ensure((size_t)cap * 16u * lights) && w.rng[0].try_ensure((size_t)cap * 32u) &&
+                      (!(multi_chunk && wf_overlap && !alpha) || w.rng[1].try_ensure((size_t)cap * 32u));
+            if (ok) break;
+            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1]})
+                b->release();
+            if (cap <= (1u << 20))
+                fail(PT_ERR_DEVICE, "out of device memory: the path queues need %zu bytes for %u work items",
+                     (size_t)cap * (240u + 16u * lights), cap);
+            cap = std::max<uint32_t>(1u << 20, (cap / 2u) & ~63u);
+        }
         if (multi_chunk && wf_overlap && !alpha) {
-            w.rng[1].ensure((size_t)cap * 32u);
             if (!w.side_rng) {
                 HIP_CHECK(hipStreamCreateWithFlags(&w.side_rng, hipStreamNonBlocking));
                 HIP_CHECK(hipEventCreateWithFlags(&w.ev_rng, hipEventDisableTiming));

@@ -451,3 +451,24 @@ def test_config5_translucent_4k(pta, oracle):
     idx = pta.local_pixel_map(prof, opts)
     r_rgb, r_acc = g.render(prof, opts)
     assert np.array_equal(bits(r_acc), bits(acc[idx])) and np.array_equal(r_rgb, rgb[idx])
+
+
+def test_out_of_memory_falls_back_to_smaller_chunks(pta, scene_cache):
+    """The path queues take 256 B per work item (one chunk = the whole frame by default).  On a device that
+    cannot provide them the render must go on with smaller chunks - same bits - instead of failing."""
+    import torch
+    scene = scene_cache("cube")
+    prof = pta.Profile.make(1920, 1080, 48, 3)            # 99.5 M work items: 25 GB of queues in one chunk
+    rgb, acc = pta.GpuScene(scene).render(prof)
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    keep = 10 << 30                                        # leave 10 GiB: forces at least two halvings
+    hog = torch.empty(max(0, free - keep), dtype=torch.uint8, device="cuda")
+    try:
+        g = pta.GpuScene(scene)
+        rgb2, acc2 = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_TIMING))
+        assert g.timing().as_dict()["launches"] > prof.bounces + 1      # several chunks were needed
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert np.array_equal(rgb2, rgb) and np.array_equal(bits(acc2), bits(acc))
