@@ -72,7 +72,32 @@ struct RenderParams {
     uint32_t shard_rank, shard_count, tile_w, tile_h;
     uint32_t tiles_x, tiles_y;
     uint32_t n_local;       // pixels rendered by this call
+    // exact division of the work-item decoding by multiply-high (pt_fastdiv, dividends < 2^27):
+    // the sample batch, the 8x8 blocks of a tile, the 8-pixel columns of a tile, the tile columns of the image
+    uint32_t div_batch[2], div_tile_blocks[2], div_tile_cols[2], div_tiles_x[2];   // {magic, shift}
 };
+
+// q = n / d for n < 2^27 with {magic, shift} from pt_fastdiv_make(d): magic = ceil(2^(32 + shift) / d),
+// shift = max(0, ceil(log2 d) - 5); the rounding error magic * d - 2^(32 + shift) < d times n < 2^27 stays below
+// 2^(32 + shift), so the quotient is exact.  d = 1 is encoded as magic 0.
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t pt_fastdiv(uint32_t n, const uint32_t (&ms)[2]) {
+    return ms[0] ? __umulhi(n, ms[0]) >> ms[1] : n;
+}
+#endif
+static inline void pt_fastdiv_make(uint32_t d, uint32_t (&ms)[2]) {
+    if (d <= 1u) {
+        ms[0] = 0u;
+        ms[1] = 0u;
+        return;
+    }
+    uint32_t s = 0;
+    while ((1u << s) < d) ++s;                       // ceil(log2 d)
+    const uint32_t shift = s > 5u ? s - 5u : 0u;
+    const unsigned long long pow = 1ull << (32u + shift);
+    ms[0] = (uint32_t)((pow + d - 1ull) / d);        // < 2^32: d > 2^(s-1) and shift >= s - 5 (d >= 2: pow / d <= 2^31 ...)
+    ms[1] = shift;
+}
 
 // Work counters (PT_FLAG_COUNTERS variant only).
 struct DevCounters {

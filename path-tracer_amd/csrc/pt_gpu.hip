@@ -814,6 +814,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     P.tiles_x = tm.tiles_x;
     P.tiles_y = tm.tiles_y;
     P.n_local = (uint32_t)tm.n_local;
+    pt_fastdiv_make((o.tile_w >> 3) * (o.tile_h >> 3), P.div_tile_blocks);
+    pt_fastdiv_make(o.tile_w >> 3, P.div_tile_cols);
+    pt_fastdiv_make(tm.tiles_x, P.div_tiles_x);
 
     // ---- integrator selection: wavefront (default), or for A/B measurements the fused
     // persistent kernel (PT_INTEGRATOR=persist) / the one-lane-per-pixel megakernel (=mega)
@@ -952,6 +955,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         P.sample_begin = s0;
         P.sample_end = std::min(p.samples, s0 + batch);
         uint32_t nb = P.sample_end - P.sample_begin;
+        pt_fastdiv_make(nb, P.div_batch);
         if (mode == 0) {
             stage_begin(5);
             if (counting)

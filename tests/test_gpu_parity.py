@@ -187,10 +187,12 @@ def test_sharded_render_is_bit_identical(pta, scene_cache, gpu_scene_cache):
     g = gpu_scene_cache("alpha_transparency")
     full_rgb, full_acc = g.render(prof)
     seen = np.zeros(prof.width * prof.height, bool)
-    for count, tile in ((2, 32), (3, 16), (8, 32)):
+    # (tile shapes and rank counts that are not powers of two exercise the multiply-high divisions of the
+    # work-item decoding: 6 x 2 = 12 blocks per tile, 4 tile columns, 5 ranks)
+    for count, tile_w, tile_h in ((2, 32, 32), (3, 16, 16), (8, 32, 32), (5, 48, 16), (7, 24, 32)):
         seen[:] = False
         for rank in range(count):
-            opts = pta.Opts.make(shard_rank=rank, shard_count=count, tile_w=tile, tile_h=tile)
+            opts = pta.Opts.make(shard_rank=rank, shard_count=count, tile_w=tile_w, tile_h=tile_h)
             idx = pta.local_pixel_map(prof, opts)
             rgb, acc = g.render(prof, opts)
             assert np.array_equal(rgb, full_rgb[idx])
@@ -230,8 +232,9 @@ def test_sample_batches_keep_accumulation_order(pta, scene_cache, gpu_scene_cach
     prof = pta.Profile.make(96, 64, 9, 2)
     g = gpu_scene_cache("cube")
     _, acc1 = g.render(prof)
-    _, acc2 = g.render(prof, pta.Opts.make(sample_batch=2))
-    assert np.array_equal(acc1.view(np.uint32), acc2.view(np.uint32))
+    for batch in (2, 3, 7):   # (odd batch sizes: the sample index is a remainder of the work-item decoding)
+        _, acc2 = g.render(prof, pta.Opts.make(sample_batch=batch))
+        assert np.array_equal(acc1.view(np.uint32), acc2.view(np.uint32))
 
 
 def test_counters_match_oracle(pta, oracle, scene_cache, gpu_scene_cache):
