@@ -114,7 +114,9 @@ PT_D uint32_t wf_reserve(uint32_t* counter, bool want) {
 // The reservation shrinks with the queue (>= ~16 reservations per wavefront, 64 ... 512 entries): with 512 a
 // launch of a few million rays gave most waves one or two reservations of 8 rays per lane, and every
 // persistent launch had a ~1 ms floor (drain of the last reservations) however short its queue.
+#ifndef WF_CHUNK
 #define WF_CHUNK 512u
+#endif
 struct WaveFetch {
     uint32_t cur, end;
     bool done;
