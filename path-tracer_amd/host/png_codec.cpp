@@ -86,7 +86,13 @@ void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32
     size_t bpp_bits = (size_t)channels * depth;
     size_t stride = ((size_t)w * bpp_bits + 7) / 8;
     size_t bpp = bpp_bits < 8 ? 1 : bpp_bits / 8;  // filter byte distance
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    // A damaged header must not drive the allocation: deflate expands at most ~1032 : 1, so the pixel data
+    // the IDAT chunks can hold bounds the image; 2^31 bytes of raw scanlines is the format limit kept here.
+    const size_t raw_size = (stride + 1) * (size_t)h;
+    if (w > (1u << 24) || h > (1u << 24) || raw_size > ((size_t)1 << 31) || raw_size / 1100 > idat.size() + 1)
+        fail(PT_ERR_PARSE, "PNG header claims %u x %u pixels, which its %zu bytes of image data cannot hold", w, h,
+             idat.size());
+    std::vector<uint8_t> raw(raw_size);
     uLongf rawlen = raw.size();
     int zr = uncompress(raw.data(), &rawlen, idat.data(), idat.size());
     if (zr != Z_OK || rawlen != raw.size()) fail(PT_ERR_PARSE, "PNG inflate failed (%d)", zr);

@@ -223,3 +223,20 @@ def test_generator_is_deterministic_and_round_trips(pta, tmp_path):
     rt = pta.HostScene.load_isf(tmp_path / "gen_alpha" / "scene.isf")
     nt = int(rt.desc.contents.n_texel_bytes)
     assert np.array_equal(np.ctypeslib.as_array(t.desc.contents.texels, (nt,)), np.ctypeslib.as_array(rt.desc.contents.texels, (nt,)))
+
+
+def test_png_with_a_lying_header_is_rejected(pta, tmp_path):
+    """A damaged IHDR must not drive the decoder's allocation (found by tools/fuzz_host.py): 60000 x 60000 pixels
+    claimed over a few hundred bytes of image data is an error, not a 10 GB buffer."""
+    import os, struct, zlib
+    rgb = (np.arange(8 * 8 * 3) % 251).astype(np.uint8).reshape(8, 8, 3)
+    path = tmp_path / "ok.png"
+    lib = pta.host_lib()
+    pta.check_host(lib.pth_png_write_rgb8(os.fsencode(str(path)), 8, 8, rgb.ctypes.data))
+    data = bytearray(path.read_bytes())
+    assert data[12:16] == b"IHDR"
+    data[16:24] = struct.pack(">II", 60000, 60000)
+    data[29:33] = struct.pack(">I", zlib.crc32(bytes(data[12:29])))   # keep the chunk CRC valid
+    w, h, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+    rc = lib.pth_png_decode(bytes(data), len(data), 3, C.byref(w), C.byref(h), C.byref(px))
+    assert rc != 0 and b"cannot hold" in lib.pth_last_error()

@@ -1,0 +1,66 @@
+"""Mutation fuzzing of the parsers that take untrusted bytes: ISF scene files, PNG textures, profile YAML.
+Every input must come back as a status code (PT_OK or an error with a message), never as a crash.  Meant to run
+against the sanitized host library:  bash tools/asan_host.sh builds it; or standalone:
+
+    python tools/fuzz_host.py [iterations] [seed]
+"""
+import ctypes as C, os, random, shutil, sys, tempfile, pathlib
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+import __graft_entry__ as e
+pta = e.load_package()
+L = pta.host_lib()
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+golden = pathlib.Path(__file__).resolve().parent.parent / "tests" / "golden"
+scenes = sorted(golden.glob("scenes/*/scene.isf")) or sorted(golden.rglob("*.isf"))
+pngs = sorted(golden.rglob("*.png"))
+assert scenes and pngs, (len(scenes), len(pngs))
+
+
+def mutate(data: bytes) -> bytes:
+    b = bytearray(data)
+    kind = rng.randrange(6)
+    if kind == 0 and len(b) > 1:                       # truncate
+        del b[rng.randrange(1, len(b)):]
+    elif kind == 1:                                    # flip random bytes
+        for _ in range(rng.randrange(1, 8)):
+            b[rng.randrange(len(b))] = rng.randrange(256)
+    elif kind == 2:                                    # delete a slice
+        i = rng.randrange(len(b)); del b[i:i + rng.randrange(1, 64)]
+    elif kind == 3:                                    # duplicate a slice
+        i = rng.randrange(len(b)); b[i:i] = b[i:i + rng.randrange(1, 64)]
+    elif kind == 4:                                    # insert structural characters / huge numbers
+        i = rng.randrange(len(b)); b[i:i] = rng.choice([b"{", b"}", b"[", b"]", b",", b":", b'"', b"1e999", b"-", b"null", b"\\u12"])
+    else:                                              # swap two regions
+        i, j = rng.randrange(len(b)), rng.randrange(len(b)); b[i], b[j] = b[j], b[i]
+    return bytes(b)
+
+
+ok = err = 0
+tmp = pathlib.Path(tempfile.mkdtemp(prefix="ptfuzz"))
+try:
+    for it in range(iters):
+        which = it % 3
+        if which == 0:     # ISF: mutated scene next to the original textures
+            src = rng.choice(scenes)
+            d = tmp / "scene"
+            if d.exists(): shutil.rmtree(d)
+            shutil.copytree(src.parent, d)
+            (d / "scene.isf").write_bytes(mutate(src.read_bytes()))
+            h = C.c_void_p()
+            rc = L.pth_scene_load_isf(os.fsencode(str(d / "scene.isf")), C.byref(h))
+            if rc == 0: L.pth_scene_free(h)
+        elif which == 1:   # PNG
+            data = mutate(rng.choice(pngs).read_bytes())
+            w, hh, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+            rc = L.pth_png_decode(data, len(data), rng.choice([1, 3]), C.byref(w), C.byref(hh), C.byref(px))
+            if rc == 0: L.pth_free(px)
+        else:              # profile YAML
+            text = mutate(b"resolution:\n  width: 64\n  height: 48\nsamples: 4\nbounces: 2\nbrdf: COOK_TORRANCE\ntonemap: FILMIC\n")
+            prof = pta.Profile()
+            rc = L.pth_profile_parse(text.replace(b"\0", b" "), C.byref(prof))
+        ok += rc == 0
+        err += rc != 0
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+print(f"{iters} mutated inputs: {ok} accepted, {err} rejected with a status code, 0 crashes")
