@@ -9,12 +9,15 @@
 // Any error prints the message on stderr and exits with code 2 (main.rs:14-22).
 // The render itself runs on the GPU through the C ABI of include/ptgpu.h;
 // there is no CPU fallback.  Extras (not in the reference): --device N,
-// --stats (prints one JSON line with timings to stderr).
+// --devices A,B,... (one host thread per GPU, each rendering its share of interleaved 32x32 tiles: the
+// sharding of SURVEY 8-e inside one process, assembled on the host), --stats (one JSON line with timings
+// on stderr).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ptgpu.h"
@@ -39,6 +42,7 @@ void usage_render(FILE* f) {
           "      --debug-textures     Generate debug textures\n"
           "  -p, --profile <PROFILE>  A path to the yaml file containing all the rendering profile information [env: PROFILE=]\n"
           "      --device <N>         HIP device ordinal [default: 0]\n"
+          "      --devices <A,B,..>   Render on several GPUs (interleaved tiles, one thread per device)\n"
           "      --stats              Print timing statistics as JSON on stderr\n"
           "  -h, --help               Print help\n",
           f);
@@ -87,6 +91,7 @@ int run_render(int argc, char** argv) {
     std::string input, output, profile_path;
     bool have_output = false, have_profile = false, quiet = false, debug_textures = false, stats = false, viewer = false;
     int device = 0;
+    std::vector<int> devices;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
         auto value = [&](const char* name) -> std::string {
@@ -115,7 +120,17 @@ int run_render(int argc, char** argv) {
         else if (a == "-qv" || a == "-vq") quiet = viewer = true;
         else if (a == "--debug-textures") debug_textures = true;
         else if (a == "--stats") stats = true;
-        else if (a == "--device" || a.rfind("--device=", 0) == 0) device = atoi(value("--device <N>").c_str());
+        else if (a == "--devices" || a.rfind("--devices=", 0) == 0) {
+            std::string list = value("--devices <A,B,..>");
+            devices.clear();
+            for (size_t p = 0; p <= list.size();) {
+                size_t q = list.find(',', p);
+                if (q == std::string::npos) q = list.size();
+                if (q == p) die("error: invalid value '" + list + "' for '--devices <A,B,..>'");
+                devices.push_back(atoi(list.substr(p, q - p).c_str()));
+                p = q + 1;
+            }
+        } else if (a == "--device" || a.rfind("--device=", 0) == 0) device = atoi(value("--device <N>").c_str());
         else if (a.size() > 1 && a[0] == '-' && a != "-")
             die("error: unexpected argument '" + a + "' found\n\nUsage: path-tracer render [OPTIONS] <INPUT>");
         else if (input.empty()) input = a;
@@ -143,8 +158,12 @@ int run_render(int argc, char** argv) {
     if (pth_scene_load_isf(input.c_str(), &hscene) != PT_OK) die(pth_last_error());
     auto t1 = std::chrono::steady_clock::now();
 
-    pt_scene* scene = nullptr;
-    if (pt_scene_create(pth_scene_desc(hscene), device, &scene) != PT_OK) die(pt_last_error());
+    if (devices.size() == 1 || (debug_textures && !devices.empty())) {
+        device = devices[0];
+        devices.clear();
+    }
+    pt_scene* scene = nullptr;   // (several devices: every worker thread creates its own below)
+    if (devices.empty() && pt_scene_create(pth_scene_desc(hscene), device, &scene) != PT_OK) die(pt_last_error());
     auto t2 = std::chrono::steady_clock::now();
 
     if (debug_textures) {  // debug_render(&scene, profile.resolution); return (main.rs:40-43)
@@ -159,6 +178,55 @@ int run_render(int argc, char** argv) {
                                        planes.data() + plane * p) != PT_OK)
                     die(pth_last_error());
         pt_scene_destroy(scene);
+        pth_scene_free(hscene);
+        return 0;
+    }
+
+    if (devices.size() > 1) {
+        // One host thread per GPU: scene + KD-tree per device, shard k of N = tiles k, k + N, ... (the global
+        // pixel index stays in the RNG seed, so the assembled image equals the single-GPU one bit for bit).
+        const uint32_t n = (uint32_t)devices.size();
+        std::vector<std::vector<uint8_t>> part(n);
+        std::vector<std::vector<uint32_t>> map(n);
+        std::vector<std::string> error(n);
+        auto worker = [&](uint32_t k) {
+            pt_opts o;
+            memset(&o, 0, sizeof o);
+            o.device = devices[k];
+            o.shard_rank = k;
+            o.shard_count = n;
+            o.tile_w = o.tile_h = 32;
+            uint64_t count = pt_local_pixel_count(&profile, &o);
+            map[k].resize(count);
+            part[k].resize(count * 3);
+            pt_scene* sc = nullptr;
+            if (pt_local_pixel_map(&profile, &o, map[k].data()) != PT_OK ||
+                pt_scene_create(pth_scene_desc(hscene), devices[k], &sc) != PT_OK ||
+                pt_render(sc, &profile, &o, part[k].data(), nullptr) != PT_OK)
+                error[k] = pt_last_error();   // (the message is thread-local: read it on this thread)
+            if (sc) pt_scene_destroy(sc);
+        };
+        std::vector<std::thread> threads;
+        for (uint32_t k = 0; k < n; ++k) threads.emplace_back(worker, k);
+        for (auto& t : threads) t.join();
+        for (uint32_t k = 0; k < n; ++k)
+            if (!error[k].empty()) die(error[k]);
+        std::vector<uint8_t> rgb((size_t)profile.width * profile.height * 3);
+        for (uint32_t k = 0; k < n; ++k)
+            for (size_t i = 0; i < map[k].size(); ++i) memcpy(&rgb[(size_t)map[k][i] * 3], &part[k][i * 3], 3);
+        auto t3 = std::chrono::steady_clock::now();
+        if (!quiet)
+            fprintf(stderr, "Done: %llds\n", (long long)std::chrono::duration_cast<std::chrono::seconds>(t3 - t2).count());
+        size_t dot = output.find_last_of('.');
+        std::string ext = dot == std::string::npos ? "" : output.substr(dot + 1);
+        for (char& c : ext) c = (char)tolower(c);
+        if (ext != "png") die("The image format could not be determined (only .png output is supported): " + output);
+        if (pth_png_write_rgb8(output.c_str(), profile.width, profile.height, rgb.data()) != PT_OK) die(pth_last_error());
+        if (stats) {
+            double sec = std::chrono::duration<double>(t3 - t2).count();
+            fprintf(stderr, "{\"devices\": %u, \"render_s\": %.3f, \"msamples_per_s\": %.2f}\n", n, sec,
+                    (double)profile.width * profile.height * profile.samples / sec / 1e6);
+        }
         pth_scene_free(hscene);
         return 0;
     }

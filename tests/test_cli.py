@@ -77,3 +77,22 @@ def test_cli_renders_like_the_library(tmp_path, pta, gpu_scene_cache):
     assert r.returncode == 0, r.stderr
     rgb, _ = gpu_scene_cache("reflection").render(pta.Profile.make(96, 64, 4, 2))
     assert np.array_equal(np.asarray(Image.open(out)).reshape(-1, 3), rgb)
+
+
+@pytest.mark.gpu
+def test_cli_several_devices_equal_one(tmp_path, pta, gpu_scene_cache):
+    """--devices A,B,..: one host thread per device, interleaved tiles, host-side assembly.  With the same
+    device listed three times the three shards run on one GPU; the image must equal the single-device one."""
+    import numpy as np
+    from PIL import Image
+    prof = tmp_path / "p.yml"
+    prof.write_text("resolution:\n  width: 150\n  height: 70\nsamples: 5\nbounces: 3\n")
+    out = tmp_path / "multi.png"
+    r = run("render", str(SCENES / "alpha_transparency" / "scene.isf"), "-q", "-p", str(prof), "-o", str(out),
+            "--devices", "0,0,0", "--stats")
+    assert r.returncode == 0, r.stderr
+    assert '"devices": 3' in r.stderr
+    rgb, _ = gpu_scene_cache("alpha_transparency").render(pta.Profile.make(150, 70, 5, 3))
+    assert np.array_equal(np.asarray(Image.open(out)).reshape(-1, 3), rgb)
+    r = run("render", str(SCENES / "cube" / "scene.isf"), "-q", "-o", str(out), "--devices", "0,,1")
+    assert r.returncode == 2 and "invalid value" in r.stderr
