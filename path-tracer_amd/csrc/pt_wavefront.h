@@ -778,13 +778,15 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
         if (!it.valid) {
             live = false;
         } else {
-            const uint2 sc = *(const uint2*)(rng_planes + i);  // jittered screen position (k_wf_rng)
-            primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
             thr = mk3(1.f, 1.f, 1.f);
             color = mk3(0.f, 0.f, 0.f);
             draw = 2;
             out_slot = (it.sample - 1u - W.P.sample_begin) * W.P.n_local + it.out_index;
             hit = unpack_hit(hits[i], h);
+            if (hit) {  // (a missed cast only adds the background: no ray, no normalisation)
+                const uint2 sc = *(const uint2*)(rng_planes + i);  // jittered screen position (k_wf_rng)
+                primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
+            }
             if (COUNT) n_new++;
         }
     }
