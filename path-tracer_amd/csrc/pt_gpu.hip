@@ -1,13 +1,17 @@
 // libptgpu.so — HIP kernels and the C ABI of include/ptgpu.h (gfx950 only).
 //
-// Kernels
-//   k_render<COUNT>   the integrator: one lane per pixel of this call's shard,
-//                     a wavefront covers an 8x8 pixel block (coherent primary
-//                     rays), samples are looped inside the lane so the f32 sum
-//                     `*pixel += color` keeps the reference's order
-//                     (renderer/mod.rs:105-130)
+// Integrators (PT_INTEGRATOR)
+//   wavefront (default)  pt_wavefront.h: k_wf_rng / k_wf_generate, then per bounce k_wf_trace (persistent),
+//                        k_wf_shade, k_wf_shadow (persistent, on a side stream beside the next trace);
+//                        k_accumulate adds the staged per-sample radiance in the reference's sample order
+//   persist              k_rng_blocks + k_render_persist: persistent lanes with path regeneration
+//   mega                 k_render<COUNT>: one lane per pixel, samples looped inside the lane
+//                        (renderer/mod.rs:105-130); kept for A/B runs and as a second implementation
+// Other kernels
 //   k_postprocess     Renderer::post_processing (mod.rs:335-353)
 //   k_assemble        scatter all-gathered packed tiles into a row-major image
+//   k_debug           --debug-textures G-buffer pass (debug_renderer.rs:64-105)
+//   k_stream_copy     achievable-HBM yardstick of the roofline (pt_measure_copy_bandwidth)
 //   k_trace / k_trace_all / k_isect / k_rng / k_math   parity-test hooks
 #include <hip/hip_runtime.h>
 
