@@ -1,7 +1,7 @@
 // libptgpu.so — HIP kernels and the C ABI of include/ptgpu.h (gfx950 only).
 //
 // Integrators (PT_INTEGRATOR)
-//   wavefront (default)  pt_wavefront.h: k_wf_rng / k_wf_generate, then per bounce k_wf_trace (persistent),
+//   wavefront (default)  pt_wavefront.h: k_wf_rng, then per bounce k_wf_trace (persistent),
 //                        k_wf_shade, k_wf_shadow (persistent, on a side stream beside the next trace);
 //                        k_accumulate adds the staged per-sample radiance in the reference's sample order
 //   persist              k_rng_blocks + k_render_persist: persistent lanes with path regeneration
@@ -540,7 +540,7 @@ struct pt_scene {
     // The queues of the chunk of work items in flight.  The shadow casts of bounce b run on a side stream
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
-        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2];
+        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws;
         hipStream_t side = nullptr, side_rng = nullptr;
         hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr;
     };
@@ -917,16 +917,17 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             bool ok = w.queue[0].try_ensure((size_t)cap * 64u) && w.queue[1].try_ensure((size_t)cap * 64u) &&
                       w.hits.try_ensure((size_t)cap * 16u) && w.shadow.try_ensure((size_t)cap * 64u) &&
                       w.contrib.try_ensure((size_t)cap * 16u * lights) && w.rng[0].try_ensure((size_t)cap * 32u) &&
-                      (!(multi_chunk && wf_overlap && !alpha) || w.rng[1].try_ensure((size_t)cap * 32u));
+                      (!(multi_chunk && wf_overlap) || w.rng[1].try_ensure((size_t)cap * 32u)) &&
+                      (!alpha || w.draws.try_ensure((size_t)cap * 4u));   // RNG draw index of the alpha walk
             if (ok) break;
-            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1]})
+            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1], &w.draws})
                 b->release();
             if (cap <= (1u << 20))
                 fail(PT_ERR_DEVICE, "out of device memory: the path queues need %zu bytes for %u work items",
                      (size_t)cap * (240u + 16u * lights), cap);
             cap = std::max<uint32_t>(1u << 20, (cap / 2u) & ~63u);
         }
-        if (multi_chunk && wf_overlap && !alpha) {
+        if (multi_chunk && wf_overlap) {
             if (!w.side_rng) {
                 HIP_CHECK(hipStreamCreateWithFlags(&w.side_rng, hipStreamNonBlocking));
                 HIP_CHECK(hipEventCreateWithFlags(&w.ev_rng, hipEventDisableTiming));
@@ -997,7 +998,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             // opaque scenes, several chunks: the RNG planes of chunk c+1 are produced on their own stream while
             // chunk c runs its bounces (k_wf_rng is pure integer ALU work; the traversal kernels leave ~40 % of
             // the issue slots idle and end in a drain phase)
-            const bool rng_ahead = !alpha && wf_overlap && total_items > cap && pipe.side_rng != nullptr;
+            const bool rng_ahead = wf_overlap && total_items > cap && pipe.side_rng != nullptr;
             uint32_t chunk_no = 0;
             for (uint32_t base = 0; base < total_items; base += cap, ++chunk_no) {
                 WfParams W{};
@@ -1010,15 +1011,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 W.walk_steps = std::max(1u, wf_walk);
                 WfCounters* wctr = (WfCounters*)pipe.ctr.p;
                 HIP_CHECK(hipMemsetAsync(wctr, 0, sizeof(WfCounters) * (p.bounces + 3), st_main));
-                // bounce 0 of opaque scenes derives the camera rays in place (no generate kernel, no queue[0])
-                const bool fused_primary = !alpha;
-                if (!fused_primary) {
-                    stage_begin(0);
-                    hipLaunchKernelGGL(k_wf_generate, dim3((W.n_items + 255u) / 256u), dim3(256), 0, st_main, s.dev, W, d_tiles,
-                                       (float4*)pipe.queue[0].p, rng_planes, wctr, gctr);
-                    HIP_CHECK(hipGetLastError());
-                    stage_end();
-                } else if (!rng_ahead || chunk_no == 0) {
+                // bounce 0 derives the camera rays in place from the staged screen positions (no queue[0])
+                const bool fused_primary = true;
+                if (!rng_ahead || chunk_no == 0) {
                     stage_begin(0);
                     hipLaunchKernelGGL(k_wf_rng, dim3((W.n_items + 255u) / 256u), dim3(256), 0, st_main, s.dev, W, d_tiles,
                                        rng_planes);
@@ -1050,7 +1045,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     const bool prim = fused_primary && b == 0;
 #define PT_LAUNCH_ACP(kernel, grid, threads, ...)                                                                                      \
     do {                                                                                                                               \
-        if (prim && counting) hipLaunchKernelGGL((kernel<false, true, true>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__);     \
+        if (prim && alpha && counting)                                                                                                  \
+            hipLaunchKernelGGL((kernel<true, true, true>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__);                        \
+        else if (prim && alpha) hipLaunchKernelGGL((kernel<true, false, true>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__);   \
+        else if (prim && counting) hipLaunchKernelGGL((kernel<false, true, true>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__); \
         else if (prim) hipLaunchKernelGGL((kernel<false, false, true>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__);           \
         else if (alpha && counting) hipLaunchKernelGGL((kernel<true, true, false>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__); \
         else if (alpha) hipLaunchKernelGGL((kernel<true, false, false>), dim3(grid), dim3(threads), 0, st_main, __VA_ARGS__);          \
@@ -1068,14 +1066,15 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     } while (0)
                     stage_begin(1);
                     PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, 256, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
-                                  (const uint4*)rng_planes, wctr, gctr);
+                                  (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, wctr, gctr);
                     stage_end();
                     ++launches;
                     // shade(b) reads the colours shadow(b-1) patched and refills the shadow queue it consumed
                     if (st_shadow != st_main && b > 0) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
                     stage_begin(2);
                     PT_LAUNCH_ACP(k_wf_shade, (uint32_t)(s.n_cu * 4 * (1024 / WF_SHADE_THREADS)), WF_SHADE_THREADS, s.dev, W, d_tiles, (const float4*)q_in,
-                                  (const uint4*)pipe.hits.p, (const uint4*)rng_planes, q_out, (float4*)pipe.shadow.p,
+                                  (const uint4*)pipe.hits.p, (const uint4*)rng_planes, (const uint32_t*)pipe.draws.p, q_out,
+                                  (float4*)pipe.shadow.p,
                                   (float4*)pipe.contrib.p,
                                   (float*)s.staging_buf.p, wctr, gctr);
                     stage_end();

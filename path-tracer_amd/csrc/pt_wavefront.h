@@ -4,10 +4,9 @@
 // other inside one fused kernel (measured: 8 of 64 lanes active per VALU instruction there).
 //
 //   per chunk of work items (one item = one path sample, pt_gpu.hip decode_item):
-//     k_wf_rng                      ChaCha12 block 0 of every item, words 0-7 staged in two 16-byte planes
-//                                   (opaque scenes: the bounce-0 trace and shade kernels derive the camera
-//                                   ray in place from words 0,1 - template parameter PRIMARY)
-//     k_wf_generate                 the same plus the camera ray -> queue[0]   (translucent scenes only)
+//     k_wf_rng                      ChaCha12 block 0 of every item, words 0-7 staged in two 16-byte planes (the
+//                                   bounce-0 trace and shade kernels derive the camera ray in place from the
+//                                   staged screen position - template parameter PRIMARY - there is no queue[0])
 //     for bounce = 0 .. bounces:
 //        k_wf_trace   (persistent)  ray_cast + alpha walk                   -> hit[i]
 //        k_wf_shade                 material, BRDF, next ray, termination   -> queue[b+1], shadow queue
@@ -425,50 +424,6 @@ PT_D bool unpack_hit(uint4 r, RawHit& h) {
 PT_D float wf_rng_float(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0f); }  // rng.gen::<f32>()
 
 // ---------------------------------------------------------------------------
-// generate: RNG block + camera ray for every valid item of the chunk
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wf_generate(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
-                                                     float4* __restrict__ queue, uint4* __restrict__ rng_planes,
-                                                     WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
-    // No compaction here: queue[0] slot = item (the only invalid items are the 8x8 blocks that
-    // hang over the image border); an invalid item is a record with out_slot = ~0 that the
-    // trace kernel answers with "no hit" and the shade kernel drops.
-    // Words 0-7 of the item's ChaCha block are staged for the consumers (see k_wf_rng).
-    uint32_t rel = blockIdx.x * 256u + threadIdx.x;
-    if (rel == 0) ctr[0].queue_count = W.n_items;
-    if (rel >= W.n_items) return;
-    ItemRef it = decode_item(W.P, tile_offsets, W.item_base + rel);
-    float4* q = queue + (size_t)rel * 4;
-    if (!it.valid) {
-        q[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        q[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        q[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        q[3] = make_float4(0.f, __uint_as_float(2u), __uint_as_float(0xffffffffu), 0.f);
-        return;
-    }
-    if (gctr) {
-        atomicAdd(&gctr->samples, 1ull);
-        atomicAdd(&gctr->rng_draws, 2ull);
-    }
-    uint32_t w[16];
-    uint64_t seed = (uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples;
-    pt_chacha12_block(seed, 0u, w);
-    float r1 = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
-    float r2 = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
-    f3 o, d;
-    float sx, sy;
-    primary_screen(S, it.x, it.y, W.P.width, W.P.height, r1, r2, sx, sy);
-    primary_from_screen(S, sx, sy, o, d);
-    uint32_t out_slot = (it.sample - 1u - W.P.sample_begin) * W.P.n_local + it.out_index;
-    q[0] = make_float4(o.x, o.y, o.z, d.x);
-    q[1] = make_float4(d.y, d.z, 1.f, 1.f);
-    q[2] = make_float4(1.f, 0.f, 0.f, 0.f);
-    q[3] = make_float4(__uint_as_float(rel), __uint_as_float(2u), __uint_as_float(out_slot), 0.f);
-    rng_planes[rel] = make_uint4(__float_as_uint(sx), __float_as_uint(sy), w[2], w[3]);
-    rng_planes[(size_t)W.cap + rel] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-
-// ---------------------------------------------------------------------------
 // rng: ChaCha12 block 0 of every item of the chunk, once, with every lane busy.  The block costs ~700
 // integer instructions; deriving it where it is consumed (in the refill of the bounce-0 trace at ~40 %
 // lane occupancy, again in the bounce-0 shade, again at every later bounce) was 15-20 % of all vector
@@ -533,14 +488,15 @@ PT_D float wf_rng_draw(WfRng& fb, const WfParams& W, const uint32_t* __restrict_
 //            non-empty leaf parks
 //   phase B  the parked lanes run Möller–Trumbore over their leaves together, then pop
 // ---------------------------------------------------------------------------
-// PRIMARY (bounce 0 of opaque scenes): there is no queue — entry i IS work item i of the chunk and the
-// camera ray is derived in place (decode + ChaCha block 0), which removes k_wf_generate's 64 B/item
-// write and this kernel's 48 B/item read.
+// PRIMARY (bounce 0): there is no queue - entry i IS work item i of the chunk and the camera ray is derived in
+// place from the screen position k_wf_rng staged (no 64 B/item ray record written and read back).  Translucent
+// scenes keep the number of rng.gen() calls of a path in draws[entry]: the alpha walk below may draw.
 template <bool ALPHA, bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES : WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W,
                                                          const uint32_t* __restrict__ tile_offsets,
                                                          float4* __restrict__ queue, uint4* __restrict__ hits,
                                                          const uint4* __restrict__ rng_planes,
+                                                         uint32_t* __restrict__ draws,
                                                          WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
     __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
@@ -604,12 +560,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
                 hit = true;
             }
             hits[idx] = pack_hit(best, hit);
-            if (ALPHA) {
-                float4* q = queue + (size_t)idx * 4;
-                float4 q3 = q[3];
-                uint32_t packed = (__float_as_uint(q3.y) & 0xffff0000u) | (draw & 0xffffu);
-                q[3] = make_float4(q3.x, __uint_as_float(packed), q3.z, q3.w);
-            }
+            if (ALPHA) draws[idx] = draw;   // rng.gen() calls of the path so far (the alpha walk may have drawn)
             active = false;
             lstate = WF_LANE_IDLE;
         }
@@ -646,6 +597,10 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
                     valid_item = sc.x != WF_ITEM_INVALID;
                     o = d = mk3(0.f, 0.f, 0.f);
                     if (valid_item) primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
+                    if (ALPHA) {
+                        item = idx;
+                        draw = 2;   // the pixel jitter
+                    }
                 } else {
                     const float4* q = queue + (size_t)idx * 4;
                     float4 q0 = q[0], q1 = q[1], q3 = q[3];
@@ -754,6 +709,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
                                                   const uint32_t* __restrict__ tile_offsets,
                                                   const float4* __restrict__ queue_in, const uint4* __restrict__ hits,
                                                   const uint4* __restrict__ rng_planes,
+                                                  const uint32_t* __restrict__ draws,
                                                   float4* __restrict__ queue_out, float4* __restrict__ shadow_q,
                                                   float4* __restrict__ contrib, float* __restrict__ staging,
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
@@ -773,14 +729,14 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
     bool hit = false;
     WfRng rng;
     rng.block = 0xffffffffu;
-    if (PRIMARY && live) {  // entry i is work item i: rebuild the path state of k_wf_generate in place
+    if (PRIMARY && live) {  // entry i is work item i: the initial path state, built in place
         ItemRef it = decode_item(W.P, tile_offsets, W.item_base + i);
         if (!it.valid) {
             live = false;
         } else {
             thr = mk3(1.f, 1.f, 1.f);
             color = mk3(0.f, 0.f, 0.f);
-            draw = 2;
+            draw = ALPHA ? draws[i] : 2u;   // 2 = the pixel jitter (+ the draws of the alpha walk)
             out_slot = (it.sample - 1u - W.P.sample_begin) * W.P.n_local + it.out_index;
             hit = unpack_hit(hits[i], h);
             if (hit) {  // (a missed cast only adds the background: no ray, no normalisation)
@@ -798,10 +754,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
         thr = mk3(q1.z, q1.w, q2.x);
         color = mk3(q2.y, q2.z, q2.w);
         item = __float_as_uint(q3.x);
-        draw = __float_as_uint(q3.y) & 0xffffu;
+        draw = ALPHA ? draws[i] : (__float_as_uint(q3.y) & 0xffffu);
         out_slot = __float_as_uint(q3.z);
         hit = unpack_hit(hits[i], h);
-        if (out_slot == 0xffffffffu) live = false;  // item outside the image (k_wf_generate)
+        if (out_slot == 0xffffffffu) live = false;  // (records of items outside the image; none since bounce 0 is fused)
     }
     const uint32_t bounce = W.bounce, bounces = W.P.bounces;
     bool to_shadow = false, survive = false;
@@ -902,7 +858,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
         out[1] = color.y;
         out[2] = color.z;
     }
-    if (COUNT && live) n_draws += PRIMARY ? draw : draw - (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu);
+    // draws made HERE (the alpha walk counts its own): since the value this kernel started from, plus the jitter
+    if (COUNT && live)
+        n_draws += draw - (ALPHA ? draws[i] : PRIMARY ? 0u : (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu)) +
+                   ((ALPHA && PRIMARY) ? 2u : 0u);
     }  // grid-stride loop
     if (COUNT && n_draws) atomicAdd(&gctr->rng_draws, (unsigned long long)n_draws);
     if (COUNT && n_new) atomicAdd(&gctr->samples, (unsigned long long)n_new);
