@@ -309,6 +309,18 @@ PT_D float material_opacity(const DevScene& S, uint32_t model, bool kind_sphere,
     return luma_channel(S, m.tex_opacity, m.opacity, uv);
 }
 
+// Opacity of the surface a raw hit belongs to (render_pixel's alpha walk, mod.rs:190-203; directional shadow
+// rays, mod.rs:289-297).  Only a material with an opacity TEXTURE needs the hit's uv - i.e. the surface record
+// with its three attribute fetches and the interpolation; everywhere else the opacity is the material's factor.
+PT_D float hit_opacity(const DevScene& S, f3 o, f3 d, const RawHit& h) {
+    const uint32_t model = __float_as_uint(S.prim_attr[(size_t)(h.pid & ~PT_PRIM_SPHERE) * 4 + 3].w);
+    const pt_material& m = S.materials[model];
+    if ((h.flags & 2u) || m.tex_opacity < 0) return m.opacity;   // spheres ignore textures (MaterialSample::simple)
+    Surface sf;
+    make_surface(S, o, d, h, sf);
+    return luma_channel(S, m.tex_opacity, m.opacity, sf.uv);
+}
+
 PT_D void material_sample(const DevScene& S, uint32_t model, bool kind_sphere, f2 uv, MatSample& r) {
     const pt_material& m = S.materials[model];
     f3 albedo = ld3(m.albedo), emissive = ld3(m.emissive);

@@ -524,9 +524,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
         bool hit = best.pid != 0xffffffffu;
         bool finished = true;
         if (ALPHA && hit) {
-            Surface sf;
-            make_surface(S, T.o, T.d, best, sf);
-            float opacity = material_opacity(S, sf.model, sf.sphere, sf.uv);
+            float opacity = hit_opacity(S, T.o, T.d, best);
             if (COUNT) lc.shaded++;
             bool stop = opacity >= 1.f;
             if (!stop && opacity > 0.001f) {
@@ -990,9 +988,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
                         opacity = material_opacity(S, smodel, sphere, uv);
                     }
                 } else {
-                    Surface sh;
-                    make_surface(S, T.o, T.d, best, sh);
-                    opacity = material_opacity(S, sh.model, sh.sphere, sh.uv);
+                    opacity = hit_opacity(S, T.o, T.d, best);
                 }
                 if (more) {
                     rad = rad * (1.f - opacity);
