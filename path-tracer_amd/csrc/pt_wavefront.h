@@ -305,9 +305,11 @@ PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float l
     // Deep lanes fetch from memory, all lanes read the (clamped) LDS slot, and the two results are merged
     // with explicit selects: they must sit in different registers, or the compiler serialises the two
     // fetches (one waits for the other's destination registers).
-    const unsigned long long deep = __builtin_amdgcn_uicmp(T.node, (uint32_t)WF_LDS_NODES, 35);  // UGE
-    uint2 g = make_uint2(0u, 0u);
-    if (T.node >= (uint32_t)WF_LDS_NODES) g = S.kd_nodes[T.node];
+    const bool is_deep = T.node >= (uint32_t)WF_LDS_NODES;
+    const unsigned long long deep = __builtin_amdgcn_ballot_w64(is_deep);
+    uint2 g;
+    asm volatile("" : "=v"(g.x), "=v"(g.y));   // (lanes that do not load keep whatever is there: they select the LDS word)
+    if (is_deep) g = S.kd_nodes[T.node];
     const uint32_t top_slot = T.node < (uint32_t)WF_LDS_NODES ? T.node : (uint32_t)WF_LDS_NODES - 1u;
     const unsigned long long e = st.top[top_slot];
     uint2 nd;
@@ -600,12 +602,16 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
                         draw = 2;   // the pixel jitter
                     }
                 } else {
+                    // (two 16-byte words of the record: these kernels run at the vector L1's request rate, ~0.97
+                    // accesses per CU-cycle, so every load a ray does not need counts; queues past bounce 0 hold
+                    // live paths only - items outside the image never leave the bounce-0 kernels)
                     const float4* q = queue + (size_t)idx * 4;
-                    float4 q0 = q[0], q1 = q[1], q3 = q[3];
+                    float4 q0 = q[0], q1 = q[1];
                     o = mk3(q0.x, q0.y, q0.z);
                     d = mk3(q0.w, q1.x, q1.y);
-                    valid_item = __float_as_uint(q3.z) != 0xffffffffu;
+                    valid_item = true;
                     if (ALPHA) {
+                        float4 q3 = q[3];
                         item = __float_as_uint(q3.x);
                         draw = __float_as_uint(q3.y) & 0xffffu;
                     }
