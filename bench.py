@@ -179,19 +179,23 @@ def main():
         # wall time of the kernel pipeline (the shadow casts overlap the next trace, so the stages do not add up)
         kernel_total = stage_ms["total_ms"] / args.steps
         pipeline = ceil_b * n_local * args.spp / (kernel_total * 1e-3) / 1e9
-        traffic = None
+        traffic = l1_rate = None
         tf = ROOT / "profiles" / "latest_traffic.json"
         if tf.exists():
             try:
                 rec = json.loads(tf.read_text())
                 if rec.get("workload") == [args.tris, args.width, args.height, args.spp, args.bounces, world]:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    l1_rate = rec.get("tcp_accesses_per_cu_cycle")
             except Exception:
                 traffic = None
         copy_gbs = pta.measure_copy_bandwidth(local_rank, 2 << 30, 5)   # achievable HBM rate on this box
         roofline = {"bound": "hbm", "kernel": "k_wf_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
+                    # from the same PMC pass as `traffic`: vector-L1 accesses per CU-cycle of this kernel (~1.1 = the
+                    # rate scattered lane accesses get through the L1: what the kernel is actually limited by)
+                    "l1_accesses_per_cu_cycle": l1_rate,
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_launch // args.steps,
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
                     "pipeline": {"algorithmic_bytes_per_sample": round(ceil_b, 1),

@@ -42,10 +42,16 @@ for name, c in acc.items():
         "valu_insts_per_cu_cycle": round(c.get("SQ_INSTS_VALU", 0) / 256 / max(1, cyc), 3),
         "salu_insts_per_cu_cycle": round(c.get("SQ_INSTS_SALU", 0) / 256 / max(1, cyc), 3),
         "kernel_ms_profiled": round(cyc / 2.1e6, 2),
+        # vector-L1 (TCP) accesses per CU and busy cycle: the traversal kernels sit at ~1.1 in every pass, whatever
+        # their length - the rate at which scattered lane accesses get through the L1
+        "tcp_accesses_per_cu_cycle": round(c.get("TCP_TOTAL_ACCESSES_sum", 0) / 256 / max(1, cyc), 3),
+        "tcp_accesses_per_vmem_inst": round(c.get("TCP_TOTAL_ACCESSES_sum", 0) /
+                                            max(1, c.get("SQ_INSTS_VMEM_RD", 0) + c.get("SQ_INSTS_VMEM_WR", 0)), 1),
     }
 json.dump({"workload": workload, "kernels": out}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 t = out["k_wf_trace"]
 json.dump({"workload": workload, "kernel": "k_wf_trace", "hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
+           "tcp_accesses_per_cu_cycle": t["tcp_accesses_per_cu_cycle"],
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_profile.sh); bytes = "
                      "(2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per 128 B "
                      "request); calibration in this pipeline: k_accumulate reads 12 B/sample -> FETCH_SIZE reads 0.48x, "
