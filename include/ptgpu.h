@@ -321,6 +321,13 @@ int pt_eval_math(int device, int fn, const float* x, uint64_t n, float* out);
  * read+write rate in GB/s (2 * bytes / time).  No reference counterpart. */
 int pt_measure_copy_bandwidth(int device, uint64_t bytes, uint32_t reps, double* gb_per_s);
 
+/* Second yardstick: scattered loads.  Every lane of every wavefront reads `bytes_per_load` (8 or 16) bytes at
+ * pseudo-random 16-byte-aligned offsets of a `table_bytes` table, `loads_per_lane` times with eight independent
+ * loads in flight; returns lane-loads per second in units of 1e9.  This is the access pattern of the KD walk, and
+ * its ceiling (not HBM bandwidth) is what k_wf_trace / k_wf_shadow run against.  No reference counterpart. */
+int pt_measure_gather_rate(int device, uint64_t table_bytes, uint32_t bytes_per_load, uint32_t loads_per_lane,
+                           double* giga_loads_per_s);
+
 const char* pt_last_error(void);
 const char* pt_version(void);
 

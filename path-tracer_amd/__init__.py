@@ -158,7 +158,8 @@ HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_s
 GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_local_pixel_count", "pt_local_pixel_map",
                "pt_render", "pt_render_device", "pt_debug_render", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
                "pt_scene_get_info", "pt_trace_rays", "pt_trace_rays_all", "pt_intersect_triangles",
-               "pt_rng_words", "pt_eval_math", "pt_measure_copy_bandwidth", "pt_last_error", "pt_version"]
+               "pt_rng_words", "pt_eval_math", "pt_measure_copy_bandwidth", "pt_measure_gather_rate", "pt_last_error",
+               "pt_version"]
 
 
 def host_lib():
@@ -225,6 +226,7 @@ def gpu_lib():
         L.pt_rng_words.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]
         L.pt_eval_math.argtypes = [C.c_int, C.c_int, vp, C.c_uint64, vp]
         L.pt_measure_copy_bandwidth.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+        L.pt_measure_gather_rate.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
         L.pt_last_error.restype = C.c_char_p
         L.pt_version.restype = C.c_char_p
         _gpu = L
@@ -391,4 +393,11 @@ def measure_copy_bandwidth(device=0, nbytes=1 << 30, reps=5):
     """GB/s (read + write) of a plain device copy kernel: the achievable-HBM yardstick."""
     out = C.c_double(0.0)
     check_gpu(gpu_lib().pt_measure_copy_bandwidth(device, nbytes, reps, C.byref(out)))
+    return out.value
+
+
+def measure_gather_rate(device=0, table_bytes=32 << 20, bytes_per_load=8, loads_per_lane=512):
+    """1e9 scattered lane-loads per second (the KD walk's access pattern): the ceiling the traversal kernels see."""
+    out = C.c_double(0.0)
+    check_gpu(gpu_lib().pt_measure_gather_rate(device, table_bytes, bytes_per_load, loads_per_lane, C.byref(out)))
     return out.value

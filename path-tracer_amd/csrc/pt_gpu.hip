@@ -438,6 +438,32 @@ __global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ 
     }
 }
 
+// scattered 8- / 16-byte loads, eight independent ones in flight per lane (pt_measure_gather_rate)
+template <int BYTES>
+__global__ __launch_bounds__(256) void k_gather(const uint4* __restrict__ table, uint32_t mask, uint32_t rounds,
+                                                uint32_t* __restrict__ sink) {
+    uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u, acc = 0;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        uint32_t idx[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            x = x * 1664525u + 1013904223u;      // LCG: a different 16-byte slot per lane and load
+            idx[k] = (x >> 8) & mask;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (BYTES == 16) {
+                uint4 v = table[idx[k]];
+                acc += v.x ^ v.w;
+            } else {
+                uint2 v = *(const uint2*)(table + idx[k]);
+                acc += v.x ^ v.y;
+            }
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;   // (keeps the loads alive)
+}
+
 __global__ __launch_bounds__(256) void k_math(int fn, const float* __restrict__ x, uint64_t n, float* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -1445,6 +1471,44 @@ int pt_measure_copy_bandwidth(int device, uint64_t bytes, uint32_t reps, double*
         (void)hipEventDestroy(e1);
         HIP_CHECK(hipGetLastError());
         *gb_per_s = 2.0 * (double)(n * 16) / ((double)best * 1e-3) / 1e9;
+    });
+}
+
+int pt_measure_gather_rate(int device, uint64_t table_bytes, uint32_t bytes_per_load, uint32_t loads_per_lane,
+                           double* giga_loads_per_s) {
+    return guarded([&] {
+        if (!giga_loads_per_s) fail(PT_ERR_INVALID, "pt_measure_gather_rate: null argument");
+        if (bytes_per_load != 8 && bytes_per_load != 16) fail(PT_ERR_INVALID, "pt_measure_gather_rate: 8 or 16 bytes per load");
+        if (table_bytes < 4096 || loads_per_lane < 8) fail(PT_ERR_INVALID, "pt_measure_gather_rate: table >= 4 KiB, loads >= 8");
+        select_device(device);
+        uint64_t slots = 1;
+        while (slots * 2 * 16 <= table_bytes) slots *= 2;   // power of two 16-byte slots
+        Staged<uint4> table(nullptr, slots);
+        Staged<uint32_t> sink(nullptr, 4);
+        HIP_CHECK(hipMemset(table.d, 0x5a, slots * 16));
+        int n_cu = 0;
+        HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
+        const uint32_t grid = (uint32_t)n_cu * 8u, rounds = loads_per_lane / 8u;   // 8 workgroups of 256 per CU
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        float best = INFINITY;
+        for (int r = 0; r < 4; ++r) {
+            HIP_CHECK(hipEventRecord(e0, 0));
+            if (bytes_per_load == 16)
+                hipLaunchKernelGGL(k_gather<16>, dim3(grid), dim3(256), 0, 0, table.d, (uint32_t)(slots - 1), rounds, sink.d);
+            else
+                hipLaunchKernelGGL(k_gather<8>, dim3(grid), dim3(256), 0, 0, table.d, (uint32_t)(slots - 1), rounds, sink.d);
+            HIP_CHECK(hipEventRecord(e1, 0));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0 && ms < best) best = ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        HIP_CHECK(hipGetLastError());
+        *giga_loads_per_s = (double)grid * 256.0 * (double)rounds * 8.0 / ((double)best * 1e-3) / 1e9;
     });
 }
 

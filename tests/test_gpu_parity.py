@@ -475,3 +475,13 @@ def test_out_of_memory_falls_back_to_smaller_chunks(pta, scene_cache):
         del hog
         torch.cuda.empty_cache()
     assert np.array_equal(rgb2, rgb) and np.array_equal(bits(acc2), bits(acc))
+
+
+def test_gather_rate_yardstick(pta):
+    """pt_measure_gather_rate: scattered 8-byte loads from an L1-resident table run at several hundred G lane-loads
+    per second on an MI355X, and an HBM-resident table is an order of magnitude slower."""
+    small = pta.measure_gather_rate(0, 16 << 10, 8, 256)
+    large = pta.measure_gather_rate(0, 1 << 30, 8, 256)
+    assert 100.0 < small < 5000.0 and 5.0 < large < small / 4, (small, large)
+    with pytest.raises(pta.PtError):
+        pta.measure_gather_rate(0, 1 << 20, 12, 256)
