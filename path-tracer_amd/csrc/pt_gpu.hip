@@ -916,10 +916,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         cap = (uint32_t)std::min<uint64_t>(items_per_batch, std::max<uint32_t>(64u, wf_cap & ~63u));
         if (s.trace_blocks == 0) {
             int a = 0, b = 0, c = 0, d = 0;
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_wf_trace<false, false, false>, 256, 0));
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_wf_trace<true, false, false>, 256, 0));
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_wf_shadow<false, false>, 256, 0));
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, k_wf_shadow<true, false>, 256, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_wf_trace<false, false, false>, WF_THREADS, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_wf_trace<true, false, false>, WF_THREADS, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_wf_shadow<false, false>, WF_THREADS, 0));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, k_wf_shadow<true, false>, WF_THREADS, 0));
             s.trace_blocks = std::max(1, alpha ? b : a) * s.n_cu;
             s.shadow_blocks = std::max(1, alpha ? d : c) * s.n_cu;
             if (const char* e = getenv("PT_WF_BLOCKS_PER_CU")) {  // experiments: fewer resident workgroups
@@ -1084,14 +1084,14 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     } while (0)
 #define PT_LAUNCH_AC(kernel, grid, ...)                                                                                  \
     do {                                                                                                                 \
-        if (alpha && counting) hipLaunchKernelGGL((kernel<true, true>), dim3(grid), dim3(256), 0, st_shadow, __VA_ARGS__); \
-        else if (alpha) hipLaunchKernelGGL((kernel<true, false>), dim3(grid), dim3(256), 0, st_shadow, __VA_ARGS__);       \
-        else if (counting) hipLaunchKernelGGL((kernel<false, true>), dim3(grid), dim3(256), 0, st_shadow, __VA_ARGS__);    \
-        else hipLaunchKernelGGL((kernel<false, false>), dim3(grid), dim3(256), 0, st_shadow, __VA_ARGS__);                 \
+        if (alpha && counting) hipLaunchKernelGGL((kernel<true, true>), dim3(grid), dim3(WF_THREADS), 0, st_shadow, __VA_ARGS__); \
+        else if (alpha) hipLaunchKernelGGL((kernel<true, false>), dim3(grid), dim3(WF_THREADS), 0, st_shadow, __VA_ARGS__);       \
+        else if (counting) hipLaunchKernelGGL((kernel<false, true>), dim3(grid), dim3(WF_THREADS), 0, st_shadow, __VA_ARGS__);    \
+        else hipLaunchKernelGGL((kernel<false, false>), dim3(grid), dim3(WF_THREADS), 0, st_shadow, __VA_ARGS__);                 \
         HIP_CHECK(hipGetLastError());                                                                                    \
     } while (0)
                     stage_begin(1);
-                    PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, 256, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
+                    PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
                                   (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, wctr, gctr);
                     stage_end();
                     ++launches;

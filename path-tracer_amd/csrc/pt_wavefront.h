@@ -168,7 +168,9 @@ PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursor, uint32_t n, bool need,
 #ifndef WF_LDS_STACK
 #define WF_LDS_STACK 8
 #endif
+#ifndef WF_THREADS
 #define WF_THREADS 256
+#endif
 #ifndef WF_MIN_WAVES
 #define WF_MIN_WAVES 1   // minimum waves per SIMD the trace/shadow kernels are compiled for
 #endif
