@@ -456,11 +456,14 @@ def test_config5_translucent_4k(pta, oracle):
     assert np.array_equal(bits(r_acc), bits(acc[idx])) and np.array_equal(r_rgb, rgb[idx])
 
 
-def test_out_of_memory_falls_back_to_smaller_chunks(pta, scene_cache):
+@pytest.mark.parametrize("name", ["cube", "alpha_transparency"])
+def test_out_of_memory_falls_back_to_smaller_chunks(pta, scene_cache, name):
     """The path queues take 256 B per work item (one chunk = the whole frame by default).  On a device that
-    cannot provide them the render must go on with smaller chunks - same bits - instead of failing."""
+    cannot provide them the render must go on with smaller chunks - same bits - instead of failing.  (Also the
+    only place several chunks per batch run in the tests: the next chunk's RNG planes are produced on a side
+    stream underneath the current chunk, for opaque and translucent scenes alike.)"""
     import torch
-    scene = scene_cache("cube")
+    scene = scene_cache(name)
     prof = pta.Profile.make(1920, 1080, 48, 3)            # 99.5 M work items: 25 GB of queues in one chunk
     rgb, acc = pta.GpuScene(scene).render(prof)
     torch.cuda.empty_cache()
