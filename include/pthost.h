@@ -91,6 +91,45 @@ uint64_t pth_prim_count(const pt_scene_desc* desc);
 int pth_kd_build(const pt_scene_desc* desc, pth_kdtree* out);
 void pth_kd_free(pth_kdtree* kd);
 
+/* ------------------------------------------------------------------ */
+/* Origin grid: candidate filter for rays through one point            */
+/* ------------------------------------------------------------------ */
+
+/* One list entry: primitive id (bit 31 = sphere) and a LOWER bound of the distance from the grid's
+ * origin to any point at which a ray can hit the primitive. */
+typedef struct pth_grid_ref {
+    uint32_t prim;
+    float mindist;
+} pth_grid_ref;
+
+/* Cube map of primitive lists around `origin` (host/origin_grid.cpp): face f = 2 * axis + (negative side),
+ * cell (iu, iv) of face f at cell_off[(f * res + iv) * res + iu], iu = floor((w[b] / |w[a]| + 1) * res / 2)
+ * with b = (a + 1) % 3, c = (a + 2) % 3 for a direction w whose largest component is w[a].  refs[0 .. n_global)
+ * are tested by every ray; a cell's list is refs[cell_off[c] .. cell_off[c + 1]), ascending (mindist, prim).
+ * Stands in for kdtree-ray (src/renderer/utils.rs:13, src/scene/internal/model.rs:67-68) for camera rays
+ * (src/renderer/mod.rs:114-124) and point-light shadow rays (src/renderer/mod.rs:301-331). */
+typedef struct pth_origin_grid {
+    float origin[3];
+    uint32_t res;            /* cells per face edge */
+    uint64_t n_cells;        /* 6 * res * res */
+    uint64_t n_refs;         /* entries of refs, the global block included */
+    uint32_t n_global;
+    uint32_t enabled;        /* 0: not built (too many global primitives, non-finite origin): use the KD-tree */
+    uint32_t max_cell_refs;
+    float ray_offset;        /* distance by which a ray may miss the origin (0 for a camera) */
+    uint32_t* cell_off;      /* malloc'd, n_cells + 1 */
+    pth_grid_ref* refs;      /* malloc'd */
+    double build_seconds;
+} pth_origin_grid;
+
+/* res = 0 chooses the resolution from the primitive count (PT_OG_RES overrides).  ray_offset: 0 for rays that
+ * start exactly AT origin; for shadow rays the largest distance between the ray's line and the origin.
+ * max_dir_len: upper bound of the length of the ray directions that will be looked up (Triangle::intersect
+ * takes the direction as it is: a camera matrix with a scale gives directions longer than 1). */
+int pth_origin_grid_build(const pt_scene_desc* desc, const float origin[3], uint32_t res, float ray_offset,
+                          float max_dir_len, pth_origin_grid* out);
+void pth_origin_grid_free(pth_origin_grid* g);
+
 const char* pth_last_error(void);
 
 #ifdef __cplusplus

@@ -132,6 +132,17 @@ class KdTree(C.Structure):
                 ("build_seconds", C.c_double), ("expected_nodes", C.c_double), ("expected_tests", C.c_double)]
 
 
+class GridRef(C.Structure):
+    _fields_ = [("prim", C.c_uint32), ("mindist", C.c_float)]
+
+
+class OriginGridC(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("res", C.c_uint32), ("n_cells", C.c_uint64), ("n_refs", C.c_uint64),
+                ("n_global", C.c_uint32), ("enabled", C.c_uint32), ("max_cell_refs", C.c_uint32),
+                ("ray_offset", C.c_float), ("cell_off", C.POINTER(C.c_uint32)), ("refs", C.POINTER(GridRef)),
+                ("build_seconds", C.c_double)]
+
+
 class OracleStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "shadow_rays", "shaded_hits", "rng_draws",
                                           "max_draws_per_sample", "numeric_errors")]
@@ -153,7 +164,7 @@ _gpu = None
 HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_scene_generate_ps5",
                 "pth_scene_save_isf", "pth_profile_load", "pth_profile_parse", "pth_png_read",
                 "pth_png_decode", "pth_png_write_rgb8", "pth_free", "pth_prim_count", "pth_kd_build",
-                "pth_kd_free", "pth_last_error"]
+                "pth_kd_free", "pth_origin_grid_build", "pth_origin_grid_free", "pth_last_error"]
 # Every symbol include/ptgpu.h declares.
 GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_local_pixel_count", "pt_local_pixel_map",
                "pt_render", "pt_render_device", "pt_debug_render", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
@@ -191,6 +202,10 @@ def host_lib():
         L.pth_kd_build.argtypes = [C.POINTER(SceneDesc), C.POINTER(KdTree)]
         L.pth_kd_free.argtypes = [C.POINTER(KdTree)]
         L.pth_kd_free.restype = None
+        L.pth_origin_grid_build.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_float), C.c_uint32, C.c_float,
+                                            C.c_float, C.POINTER(OriginGridC)]
+        L.pth_origin_grid_free.argtypes = [C.POINTER(OriginGridC)]
+        L.pth_origin_grid_free.restype = None
         L.pth_last_error.restype = C.c_char_p
         _host = L
     return _host
@@ -281,6 +296,61 @@ class HostScene:
         if self.handle:
             host_lib().pth_scene_free(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OriginGrid:
+    """pth_origin_grid (host/origin_grid.cpp): cube map of primitive lists around one point, with the cell lookup
+    restated in numpy f32 exactly as the device computes it (csrc/pt_grid.h og_cell)."""
+
+    def __init__(self, host_scene, origin, res=0, ray_offset=0.0, max_dir_len=1.001):
+        import numpy as np
+        self.c = OriginGridC()
+        o = (C.c_float * 3)(*[float(v) for v in origin])
+        check_host(host_lib().pth_origin_grid_build(host_scene.desc, o, res, ray_offset, max_dir_len, C.byref(self.c)))
+        self.enabled = bool(self.c.enabled)
+        self.res, self.n_global, self.n_refs = int(self.c.res), int(self.c.n_global), int(self.c.n_refs)
+        if self.enabled:
+            self.cell_off = np.ctypeslib.as_array(self.c.cell_off, (int(self.c.n_cells) + 1,))
+            raw = np.ctypeslib.as_array(C.cast(self.c.refs, C.POINTER(C.c_uint32)), (max(1, self.n_refs) * 2,))
+            self.ref_prim = raw[0::2]
+            self.ref_mindist = raw[1::2].view(np.float32)
+
+    def cells(self, w):
+        """Cell index of every direction w [n, 3] (f32 arithmetic of the device)."""
+        import numpy as np
+        w = np.ascontiguousarray(w, np.float32).reshape(-1, 3)
+        a = np.abs(w)
+        axis = np.where((a[:, 0] >= a[:, 1]) & (a[:, 0] >= a[:, 2]), 0, np.where(a[:, 1] >= a[:, 2], 1, 2))
+        idx = np.arange(len(w))
+        wa, wb, wc = w[idx, axis], w[idx, (axis + 1) % 3], w[idx, (axis + 2) % 3]
+        with np.errstate(all="ignore"):
+            inv = np.float32(1.0) / np.abs(wa)
+            half = np.float32(0.5 * self.res)
+            fu = (wb * inv + np.float32(1.0)) * half
+            fv = (wc * inv + np.float32(1.0)) * half
+        top = np.float32(self.res - 1)
+        iu = np.where(fu >= 0, np.minimum(np.floor(fu), top), 0)   # NaN -> 0, like the device's clamp
+        iv = np.where(fv >= 0, np.minimum(np.floor(fv), top), 0)
+        iu = np.nan_to_num(iu).astype(np.int64)
+        iv = np.nan_to_num(iv).astype(np.int64)
+        face = 2 * axis + (wa < 0)
+        return (face * self.res + iv) * self.res + iu
+
+    def candidates(self, cell):
+        """(primitive words, mindist) of one cell, the global block in front."""
+        import numpy as np
+        b, e = int(self.cell_off[cell]), int(self.cell_off[cell + 1])
+        sel = np.r_[0:self.n_global, b:e]
+        return self.ref_prim[sel], self.ref_mindist[sel]
+
+    def close(self):
+        host_lib().pth_origin_grid_free(C.byref(self.c))
 
     def __del__(self):
         try:

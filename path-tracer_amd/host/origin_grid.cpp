@@ -1,0 +1,512 @@
+// Origin grids: a second candidate filter in front of Triangle::intersect / Model::intersect, for
+// the ray populations of the path that all pass through ONE point.
+//
+// In the reference every ray_cast() (src/renderer/utils.rs:11-21) goes through the kdtree-ray
+// filter, whatever the ray.  Two populations are special, though:
+//   * camera rays (src/renderer/mod.rs:114-124): the origin is camera column 3, bit for bit the
+//     same for every sample of every pixel - 71 % of all closest-hit casts of BASELINE config 3;
+//   * shadow rays towards a point light (src/renderer/mod.rs:301-331): origin = hit + normal * 1e-5,
+//     direction = -normalize(hit - light): they all pass within 1e-5 * |normal| of the light.
+// For rays through a common point O visibility is a 2-D problem: the directions around O are cut
+// into the cells of a cube map (6 faces x res x res, uniform in the tangent plane), and every cell
+// keeps the list of primitives whose projection from O overlaps it, sorted by their distance from
+// O.  A cast is then ONE table lookup plus Möller–Trumbore over a handful of primitives - instead
+// of ~20 dependent KD-node fetches taken by 64 diverging lanes - and neighbouring rays read the
+// same lists.  The reference's result depends only on the SET of primitives whose intersect()
+// succeeds, so the filter must be conservative, never exact:
+//   * the projection is computed in f64 and grown by `margin` cells: a base margin for the f32
+//     rounding of the device's cell lookup, plus, per triangle, the slop of the f32 Möller–Trumbore
+//     itself (a grazing triangle accepts hits whose exact intersection point lies outside it by
+//     ~16 eps D^2 |e1||e2| / (|n| h), h = distance from O to the triangle's plane), plus, for a
+//     light, the angle by which a shadow ray can miss O;
+//   * a triangle that no ray through O can hit with |det| >= 1e-6 (triangle.rs:48: the silhouette triangles of
+//     a fine mesh seen edge-on) is left out; a primitive whose margin would exceed `PT_OG_MAX_MARGIN` cells, that
+//     comes closer to O than `near_radius`, or that is degenerate goes to the GLOBAL list every ray tests;
+//   * the stored distance of a primitive is a lower bound (f64 minimum distance, minus the slop,
+//     rounded down), so "stop at the first primitive farther than the best hit / the light" is safe.
+// A grid with too many global primitives is not built (enabled = 0) and the casts stay on the KD-tree.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <thread>
+
+#include "host_common.hpp"
+
+namespace pth {
+namespace {
+
+constexpr double kEps32 = 5.9604644775390625e-8;  // 2^-24
+constexpr int kMaxPoly = 24;                      // octagon clipped by four planes: <= 12 vertices
+
+struct Vec {
+    double x, y, z;
+};
+inline Vec operator-(Vec a, Vec b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec operator+(Vec a, Vec b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec operator*(Vec a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(Vec a, Vec b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline Vec cross(Vec a, Vec b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double len(Vec a) { return std::sqrt(dot(a, a)); }
+inline double comp(Vec a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// Distance from the origin to triangle (a, b, c) (Ericson, Real-Time Collision Detection 5.1.5).
+double origin_triangle_distance(Vec a, Vec b, Vec c) {
+    const Vec p{0, 0, 0};
+    Vec ab = b - a, ac = c - a, ap = p - a;
+    double d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0 && d2 <= 0) return len(a);
+    Vec bp = p - b;
+    double d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0 && d4 <= d3) return len(b);
+    double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) return len(a + ab * (d1 / (d1 - d3)));
+    Vec cp = p - c;
+    double d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0 && d5 <= d6) return len(c);
+    double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) return len(a + ac * (d2 / (d2 - d6)));
+    double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) return len(b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6))));
+    double denom = 1.0 / (va + vb + vc);
+    return len(a + ab * (vb * denom) + ac * (vc * denom));
+}
+
+struct Footprint {       // what one primitive contributes to the grid
+    bool skip = false;   // never intersected by anything (kept out)
+    bool global = false; // tested by every ray
+    int n = 0;           // polygon (relative to O) whose projection covers the primitive
+    Vec poly[8];
+    double margin = 0;   // cells
+    float mindist = 0;   // lower bound of |hit - O|
+};
+
+struct GridParams {
+    Vec origin;
+    uint32_t res;
+    double base_margin;   // cells
+    double max_margin;    // cells
+    double near_radius;   // world units
+    double ray_offset;    // world units by which a ray may miss O (0: camera)
+    double max_dir_len;   // longest ray direction (Triangle::intersect does not normalise it)
+    double abs_slack;     // world units subtracted from every stored distance
+};
+
+float round_down(double v) {
+    if (!(v > 0)) return 0.f;
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, 0.f);
+    return f;
+}
+
+Footprint triangle_footprint(const GridParams& P, const float* v) {
+    Footprint fp;
+    Vec a{v[0], v[1], v[2]}, b{v[8], v[9], v[10]}, c{v[16], v[17], v[18]};
+    a = a - P.origin;
+    b = b - P.origin;
+    c = c - P.origin;
+    Vec e1 = b - a, e2 = c - a, n = cross(e1, e2);
+    const double l1 = len(e1), l2 = len(e2), ln = len(n), lmax = std::max(l1, l2);
+    const double dmax = std::max(len(a), std::max(len(b), len(c)));
+    if (!std::isfinite(dmax) || !std::isfinite(ln)) {
+        fp.global = true;   // non-finite vertex: whatever the f32 test makes of it, every ray sees it
+        return fp;
+    }
+    // ---- error model of the f32 Möller–Trumbore (triangle.rs:37-82) for a ray of length <= dl from (about) O:
+    //   det = e1 . (d x e2)            computed with absolute error <= e_det
+    //   u, v = (t . p, d . q) / det    numerators computed with absolute error <= e_num  (|t| <= dmax)
+    // A hit is only accepted with |det| >= 1e-6, i.e. with a true determinant of at least thr.
+    const double dl = P.max_dir_len;
+    // (first-order rounding analysis: cross product 2 sqrt(3) eps |a||b|, dot product 3 eps |a||b|, the f32 difference
+    // o - v0 eps |t|: 6.5 eps |d||e1||e2| for det, 7.5 eps |d||t||e| for the numerators; 10 leaves a margin)
+    const double e_det = 10.0 * kEps32 * dl * l1 * l2;
+    const double e_num = 10.0 * kEps32 * dl * dmax * lmax;
+    const double thr = 1e-6 * (1.0 - 1e-5) - e_det;
+    const double dmin = origin_triangle_distance(a, b, c);
+    const double h = ln > 0 ? std::fabs(dot(n, a)) / ln : 0.0;   // distance from O to the triangle's plane
+    // world-space distance (in the triangle's plane) by which an accepted hit may lie outside the exact triangle:
+    // two bounds, either is valid.  (1) the true determinant of an accepted ray is >= thr;  (2) the ray meets the
+    // plane at distance D_P <= dmax + slop from O, where its true determinant is dl |n| h / D_P.
+    double slop = INFINITY;
+    if (thr > 0) {
+        slop = (e_num + e_det) / thr * (l1 + l2);
+        // accepted rays meet the plane no farther than h dl |n| / thr from O: if even that (plus the slop) does not
+        // reach the triangle, no ray through O is ever accepted - the silhouette triangles of a fine mesh
+        if ((h + P.ray_offset) * dl * ln / thr + slop + P.ray_offset < dmin * (1.0 - 1e-6)) {
+            fp.skip = true;
+            return fp;
+        }
+    }
+    if (ln > 0 && h > P.ray_offset) {
+        const double k = (e_num + e_det) * (l1 + l2) / (dl * ln * (h - P.ray_offset));   // slop = k (dmax + slop)
+        if (k < 0.5) slop = std::min(slop, k * dmax / (1.0 - k));
+    }
+    const double reach = dmin - slop - P.ray_offset;   // nearest point of O at which a ray can be accepted
+    if (!(reach >= P.near_radius) || !(reach > 0.25 * dmin)) {
+        fp.global = true;
+        return fp;
+    }
+    const double cell_angle = 2.0 / P.res;   // at the face centre, where a cell subtends the largest angle
+    // a tangent-plane coordinate moves by up to 3x the angle (du/dtheta = 1 + u^2 <= 2 on an axis, corners beyond)
+    const double margin = P.base_margin + 3.0 * ((slop + P.ray_offset) / reach) / cell_angle;
+    if (!(margin <= P.max_margin)) {
+        fp.global = true;
+        return fp;
+    }
+    fp.n = 3;
+    fp.poly[0] = a;
+    fp.poly[1] = b;
+    fp.poly[2] = c;
+    fp.margin = margin;
+    fp.mindist = round_down((reach - P.abs_slack) * (1.0 - 1e-5));
+    return fp;
+}
+
+Footprint sphere_footprint(const GridParams& P, const pt_model& mo) {
+    Footprint fp;
+    Vec c{mo.center[0], mo.center[1], mo.center[2]};
+    c = c - P.origin;
+    double r = std::fabs((double)mo.radius), D = len(c);
+    if (!std::isfinite(D) || !std::isfinite(r)) {
+        fp.global = true;
+        return fp;
+    }
+    double dmin = D - r;
+    // the silhouette cone has sin(alpha) = r / D; the f32 discriminant moves a grazing silhouette by ~2 eps / alpha,
+    // and the ray offset by ray_offset / dmin: both go into the margin; a cone wider than ~80 degrees is not worth it
+    if (!(dmin >= P.near_radius) || !(dmin > 0.02 * D)) {
+        fp.global = true;
+        return fp;
+    }
+    double sin_a = r / D, tan_a = sin_a / std::sqrt(1.0 - sin_a * sin_a);
+    double cell_angle = 2.0 / P.res;
+    double slop_angle = sin_a > 0 ? 64.0 * kEps32 / sin_a : 0.0;
+    double margin = P.base_margin + 3.0 * (slop_angle + P.ray_offset / dmin) / cell_angle;
+    if (!(margin <= P.max_margin)) {
+        fp.global = true;
+        return fp;
+    }
+    // octagon around the cone's cross-section in the plane through the centre, perpendicular to the axis
+    Vec axis = c * (1.0 / D);
+    Vec t = std::fabs(axis.x) < 0.6 ? Vec{1, 0, 0} : Vec{0, 1, 0};
+    Vec u = cross(axis, t);
+    u = u * (1.0 / len(u));
+    Vec w = cross(axis, u);
+    double rad = D * tan_a * 1.002 / std::cos(M_PI / 8);
+    fp.n = 8;
+    for (int k = 0; k < 8; ++k) {
+        double ang = 2 * M_PI * k / 8;
+        fp.poly[k] = c + u * (rad * std::cos(ang)) + w * (rad * std::sin(ang));
+    }
+    fp.margin = margin;
+    fp.mindist = round_down((dmin - P.ray_offset - P.abs_slack - 64.0 * kEps32 * D) * (1.0 - 1e-5));
+    return fp;
+}
+
+// Clip polygon (in, n) against the half-space k . p >= 0 (a plane through the origin).
+int clip_plane(const Vec* in, int n, Vec k, Vec* out) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        Vec p = in[i], q = in[(i + 1) % n];
+        double dp = dot(k, p), dq = dot(k, q);
+        if (dp >= 0) out[m++] = p;
+        if ((dp >= 0) != (dq >= 0)) {
+            double t = dp / (dp - dq);
+            out[m++] = p + (q - p) * t;
+        }
+    }
+    return m;
+}
+
+// Calls emit(cell) for every cell of every face whose (margin-grown) square the projection of the footprint may touch.
+template <class Emit>
+void rasterize(const GridParams& P, const Footprint& fp, Emit&& emit) {
+    const uint32_t R = P.res;
+    const double half = 0.5 * R, m = fp.margin, mu = m * 2.0 / R;
+    for (int face = 0; face < 6; ++face) {
+        const int a = face >> 1, b = (a + 1) % 3, c = (a + 2) % 3;
+        const double s = (face & 1) ? -1.0 : 1.0;
+        // pyramid of the face, grown by the margin: |p_b| <= (1 + mu) s p_a, |p_c| <= (1 + mu) s p_a
+        Vec buf[2][kMaxPoly];
+        int n = fp.n, cur = 0;
+        for (int i = 0; i < n; ++i) buf[0][i] = fp.poly[i];
+        for (int side = 0; side < 4 && n > 0; ++side) {
+            double k[3] = {0, 0, 0};
+            k[a] = (1.0 + mu) * s;
+            k[side < 2 ? b : c] = (side & 1) ? 1.0 : -1.0;
+            n = clip_plane(buf[cur], n, Vec{k[0], k[1], k[2]}, buf[cur ^ 1]);
+            cur ^= 1;
+        }
+        if (n == 0) continue;
+        double px[kMaxPoly], py[kMaxPoly];
+        double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+        bool all = false;
+        for (int i = 0; i < n; ++i) {
+            double wa = s * comp(buf[cur][i], a);
+            if (!(wa > 1e-300)) {   // the footprint reaches O itself (near_radius normally prevents this)
+                all = true;
+                break;
+            }
+            px[i] = (comp(buf[cur][i], b) / wa + 1.0) * half;
+            py[i] = (comp(buf[cur][i], c) / wa + 1.0) * half;
+            x0 = std::min(x0, px[i]);
+            x1 = std::max(x1, px[i]);
+            y0 = std::min(y0, py[i]);
+            y1 = std::max(y1, py[i]);
+        }
+        if (all) {
+            x0 = y0 = 0;
+            x1 = y1 = R;
+        }
+        auto cell_lo = [&](double v) { return (uint32_t)std::min<double>(R - 1, std::max(0.0, std::floor(v - m))); };
+        auto cell_hi = [&](double v) { return (uint32_t)std::min<double>(R - 1, std::max(0.0, std::floor(v + m))); };
+        uint32_t ix0 = cell_lo(x0), ix1 = cell_hi(x1), iy0 = cell_lo(y0), iy1 = cell_hi(y1);
+        // edge functions of the projected (convex) polygon: a cell is dropped when its grown square lies
+        // entirely outside one edge.  Slivers (no reliable orientation) and tiny boxes keep the whole box.
+        double area2 = 0;
+        if (!all)
+            for (int i = 0; i < n; ++i) {
+                int j = (i + 1) % n;
+                area2 += px[i] * py[j] - px[j] * py[i];
+            }
+        const bool trim = !all && (ix1 - ix0 >= 2 || iy1 - iy0 >= 2) && std::fabs(area2) > 1e-6;
+        const double orient = area2 > 0 ? 1.0 : -1.0;
+        const size_t face_base = (size_t)face * R * R;
+        for (uint32_t iy = iy0; iy <= iy1; ++iy)
+            for (uint32_t ix = ix0; ix <= ix1; ++ix) {
+                if (trim) {
+                    const double cx0 = ix - m, cx1 = ix + 1.0 + m, cy0 = iy - m, cy1 = iy + 1.0 + m;
+                    bool outside = false;
+                    for (int i = 0; i < n && !outside; ++i) {
+                        int j = (i + 1) % n;
+                        // inside(p) = orient * cross(edge, p - v_i) >= 0; take the corner that maximises it
+                        double ex = px[j] - px[i], ey = py[j] - py[i];
+                        double nx = -ey * orient, ny = ex * orient;   // inward normal
+                        double cx = nx >= 0 ? cx1 : cx0, cy = ny >= 0 ? cy1 : cy0;
+                        double val = nx * (cx - px[i]) + ny * (cy - py[i]);
+                        // (an absolute epsilon in cell^2 units keeps touching cells)
+                        if (val < -1e-9 * (std::fabs(nx) + std::fabs(ny)) * R) outside = true;
+                    }
+                    if (outside) continue;
+                }
+                emit(face_base + (size_t)iy * R + ix);
+            }
+    }
+}
+
+struct Builder {
+    const pt_scene_desc& d;
+    GridParams P;
+    std::vector<Footprint> fps;       // per primitive
+    std::vector<uint32_t> prim_word;  // primitive id | sphere bit
+
+    Builder(const pt_scene_desc& desc, const GridParams& params) : d(desc), P(params) {}
+
+    void footprints() {
+        uint64_t n_prims = pth_prim_count(&d);
+        fps.resize(n_prims);
+        prim_word.resize(n_prims);
+        uint64_t prim = 0;
+        struct Span {
+            uint64_t prim0;
+            uint32_t model;
+        };
+        std::vector<Span> spans;
+        for (uint32_t m = 0; m < d.n_models; ++m) {
+            spans.push_back({prim, m});
+            prim += d.models[m].kind == PT_MODEL_MESH ? d.models[m].tri_count : 1;
+        }
+        parallel(spans.size(), [&](size_t si, size_t) {
+            const pt_model& mo = d.models[spans[si].model];
+            uint64_t p = spans[si].prim0;
+            if (mo.kind == PT_MODEL_MESH) {
+                for (uint32_t t = 0; t < mo.tri_count; ++t, ++p) {
+                    fps[p] = triangle_footprint(P, d.triangles + (size_t)(mo.tri_first + t) * 24);
+                    prim_word[p] = (uint32_t)p;
+                }
+            } else {
+                fps[p] = sphere_footprint(P, mo);
+                prim_word[p] = (uint32_t)p | 0x80000000u;
+            }
+        });
+    }
+
+    // fn(index, thread) over [0, n) on every hardware thread, dynamic chunks
+    template <class F>
+    static void parallel(size_t n, F&& fn, size_t chunk = 1) {
+        unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        if (const char* e = getenv("PT_HOST_THREADS")) nt = std::max(1, atoi(e));
+        if (n <= chunk || nt == 1) {
+            for (size_t i = 0; i < n; ++i) fn(i, 0);
+            return;
+        }
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                while (true) {
+                    size_t b = next.fetch_add(chunk);
+                    if (b >= n) break;
+                    for (size_t i = b; i < std::min(n, b + chunk); ++i) fn(i, t);
+                }
+            });
+        for (auto& x : th) x.join();
+    }
+};
+
+uint32_t auto_resolution(uint64_t n_prims) {
+    if (const char* e = getenv("PT_OG_RES")) {
+        int v = atoi(e);
+        if (v > 0) return (uint32_t)std::min(8192, std::max(8, v));
+    }
+    // cells about half the edge of a typical triangle: ~4 sqrt(n) cells across the 90 degrees of a face
+    double want = 4.0 * std::sqrt((double)std::max<uint64_t>(1, n_prims));
+    uint32_t r = 32;
+    while (r < want && r < 4096) r *= 2;
+    return r;
+}
+
+void build(const pt_scene_desc& d, const float origin[3], uint32_t res, float ray_offset, float max_dir_len,
+           pth_origin_grid& g) {
+    auto t0 = std::chrono::steady_clock::now();
+    memset(&g, 0, sizeof g);
+    memcpy(g.origin, origin, 12);
+    const uint64_t n_prims = pth_prim_count(&d);
+    if (res == 0) res = auto_resolution(n_prims);
+    if (res > 8192) fail(PT_ERR_INVALID, "origin grid: resolution %u too large", res);
+    g.res = res;
+    g.n_cells = 6ull * res * res;
+    g.ray_offset = ray_offset;
+    if (!std::isfinite(origin[0]) || !std::isfinite(origin[1]) || !std::isfinite(origin[2])) return;  // enabled = 0
+
+    // scene extent (for the absolute slack of the stored distances)
+    double ext = 0;
+    for (uint64_t t = 0; t < d.n_triangles; ++t)
+        for (int k = 0; k < 3; ++k)
+            for (int a = 0; a < 3; ++a) {
+                double v = std::fabs((double)d.triangles[t * 24 + k * 8 + a] - origin[a]);
+                if (std::isfinite(v)) ext = std::max(ext, v);
+            }
+    for (uint32_t m = 0; m < d.n_models; ++m)
+        if (d.models[m].kind == PT_MODEL_SPHERE)
+            for (int a = 0; a < 3; ++a) {
+                double v = std::fabs((double)d.models[m].center[a] - origin[a]) + std::fabs((double)d.models[m].radius);
+                if (std::isfinite(v)) ext = std::max(ext, v);
+            }
+    GridParams P;
+    P.origin = Vec{origin[0], origin[1], origin[2]};
+    P.res = res;
+    P.base_margin = 0.125;
+    P.max_margin = 128.0;
+    P.max_dir_len = max_dir_len;
+    if (const char* e = getenv("PT_OG_MAX_MARGIN")) P.max_margin = std::max(0.5, atof(e));
+    // (the f32 rounding of the normalised shadow-ray direction moves the far end of the ray by ~1e-7 of its length)
+    P.ray_offset = ray_offset > 0 ? ray_offset + 4e-7 * ext : 0.0;
+    P.abs_slack = 1e-6 * ext + 1e-30;
+    // a ray that misses O by ray_offset deviates by ray_offset / distance: at most 1/8 cell beyond near_radius
+    P.near_radius = std::max(1e-5 * ext, P.ray_offset > 0 ? 3.0 * P.ray_offset / (0.125 * 2.0 / res) : 0.0);
+
+    Builder B(d, P);
+    B.footprints();
+    std::vector<uint32_t> global;
+    for (uint64_t p = 0; p < n_prims; ++p)
+        if (B.fps[p].global) global.push_back((uint32_t)p);
+    g.n_global = (uint32_t)global.size();
+    uint32_t max_global = 64;
+    if (const char* e = getenv("PT_OG_MAX_GLOBAL")) max_global = (uint32_t)std::max(0, atoi(e));
+    if (global.size() > max_global) {
+        g.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return;   // enabled = 0: too many primitives every ray would have to test
+    }
+
+    // ---- pass 1: count the references of every cell
+    std::unique_ptr<uint32_t, void (*)(void*)> counts((uint32_t*)calloc(g.n_cells + 1, 4), free);
+    if (!counts) throw std::bad_alloc();
+    uint32_t* cnt = counts.get();
+    const size_t chunk = 256;
+    Builder::parallel((n_prims + chunk - 1) / chunk, [&](size_t ci, size_t) {
+        for (uint64_t p = ci * chunk; p < std::min<uint64_t>(n_prims, (ci + 1) * chunk); ++p) {
+            const Footprint& fp = B.fps[p];
+            if (fp.skip || fp.global) continue;
+            rasterize(P, fp, [&](size_t cell) { __atomic_fetch_add(&cnt[cell], 1u, __ATOMIC_RELAXED); });
+        }
+    });
+    // ---- exclusive scan (the global list sits in front)
+    uint64_t total = global.size();
+    for (uint64_t c = 0; c < g.n_cells; ++c) {
+        uint32_t n = cnt[c];
+        if (total > 0xffffffffull) fail(PT_ERR_UNSUPPORTED, "origin grid: more than 2^32 references (lower PT_OG_RES)");
+        cnt[c] = (uint32_t)total;
+        total += n;
+    }
+    if (total > 0xffffffffull) fail(PT_ERR_UNSUPPORTED, "origin grid: more than 2^32 references (lower PT_OG_RES)");
+    cnt[g.n_cells] = (uint32_t)total;
+    g.n_refs = total;
+    std::unique_ptr<pth_grid_ref, void (*)(void*)> refs((pth_grid_ref*)malloc(std::max<uint64_t>(1, total) * sizeof(pth_grid_ref)), free);
+    std::unique_ptr<uint32_t, void (*)(void*)> cursor((uint32_t*)malloc((g.n_cells + 1) * 4), free);
+    if (!refs || !cursor) throw std::bad_alloc();
+    memcpy(cursor.get(), cnt, (g.n_cells + 1) * 4);
+    for (size_t i = 0; i < global.size(); ++i) refs.get()[i] = pth_grid_ref{B.prim_word[global[i]], 0.f};
+    // ---- pass 2: fill
+    uint32_t* cur = cursor.get();
+    pth_grid_ref* rf = refs.get();
+    Builder::parallel((n_prims + chunk - 1) / chunk, [&](size_t ci, size_t) {
+        for (uint64_t p = ci * chunk; p < std::min<uint64_t>(n_prims, (ci + 1) * chunk); ++p) {
+            const Footprint& fp = B.fps[p];
+            if (fp.skip || fp.global) continue;
+            const pth_grid_ref r{B.prim_word[p], fp.mindist};
+            rasterize(P, fp, [&](size_t cell) { rf[__atomic_fetch_add(&cur[cell], 1u, __ATOMIC_RELAXED)] = r; });
+        }
+    });
+    // ---- every list in ascending (distance, primitive) order: deterministic, and what the early exits need
+    const size_t cell_chunk = 4096;
+    std::atomic<uint32_t> longest{0};
+    Builder::parallel((g.n_cells + cell_chunk - 1) / cell_chunk, [&](size_t ci, size_t) {
+        uint32_t local_max = 0;
+        for (uint64_t c = ci * cell_chunk; c < std::min<uint64_t>(g.n_cells, (ci + 1) * cell_chunk); ++c) {
+            uint32_t b = cnt[c], e = cnt[c + 1];
+            local_max = std::max(local_max, e - b);
+            if (e - b > 1)
+                std::sort(rf + b, rf + e, [](const pth_grid_ref& x, const pth_grid_ref& y) {
+                    return x.mindist < y.mindist || (x.mindist == y.mindist && x.prim < y.prim);
+                });
+        }
+        uint32_t seen = longest.load();
+        while (local_max > seen && !longest.compare_exchange_weak(seen, local_max)) {
+        }
+    });
+    g.max_cell_refs = longest.load();
+    g.cell_off = counts.release();
+    g.refs = refs.release();
+    g.enabled = 1;
+    g.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+}  // namespace pth
+
+extern "C" {
+
+int pth_origin_grid_build(const pt_scene_desc* desc, const float origin[3], uint32_t res, float ray_offset,
+                          float max_dir_len, pth_origin_grid* out) {
+    return pth::guarded([&] {
+        if (!desc || !origin || !out) pth::fail(PT_ERR_INVALID, "pth_origin_grid_build: null argument");
+        if (!(ray_offset >= 0.f)) pth::fail(PT_ERR_INVALID, "pth_origin_grid_build: ray_offset must be >= 0");
+        if (!(max_dir_len > 0.f && max_dir_len < 1e6f)) pth::fail(PT_ERR_INVALID, "pth_origin_grid_build: bad max_dir_len");
+        pth::build(*desc, origin, res, ray_offset, max_dir_len, *out);
+    });
+}
+
+void pth_origin_grid_free(pth_origin_grid* g) {
+    if (!g) return;
+    free(g->cell_off);
+    free(g->refs);
+    g->cell_off = nullptr;
+    g->refs = nullptr;
+    g->enabled = 0;
+}
+
+}  // extern "C"
