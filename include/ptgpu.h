@@ -147,6 +147,10 @@ enum {
     PT_FLAG_TIMING = 1u << 0,   /* record HIP events around every kernel launch */
     PT_FLAG_COUNTERS = 1u << 1, /* run the instrumented kernel variant (ray /
                                    node / triangle counters; not for timing)  */
+    PT_FLAG_NO_GRIDS = 1u << 2, /* cast camera and shadow rays through the KD-tree like every other ray
+                                   (A/B measurements; the parity tests compare the two paths)          */
+    PT_FLAG_MEGAKERNEL = 1u << 3, /* the one-lane-per-pixel integrator (k_render): a second, independent
+                                   implementation of the path for cross-checks; ~10x slower            */
 };
 
 /* Which pixels this call renders.  The image is cut into tile_w x tile_h
@@ -274,6 +278,12 @@ typedef struct pt_scene_info {
     float kd_build_seconds;
     float upload_seconds;
     uint64_t device_bytes;
+    /* origin grids (cube maps of primitive lists around the camera / the point lights, csrc/pt_grid.h) */
+    uint32_t cam_grid_res;    /* cells per face edge; 0 = camera rays use the KD-tree */
+    uint32_t light_grids;     /* lights whose shadow rays use a grid (all or none)    */
+    uint64_t grid_refs;       /* list entries of all grids                            */
+    float grid_build_seconds;
+    uint32_t _pad;
 } pt_scene_info;
 int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out);
 

@@ -19,7 +19,7 @@ PT_OK = 0
 PT_MODEL_MESH, PT_MODEL_SPHERE = 0, 1
 PT_LIGHT_POINT, PT_LIGHT_DIRECTIONAL = 0, 1
 PT_TONEMAP_REINHARD, PT_TONEMAP_FILMIC, PT_TONEMAP_ACES = 0, 1, 2
-PT_FLAG_TIMING, PT_FLAG_COUNTERS = 1, 2
+PT_FLAG_TIMING, PT_FLAG_COUNTERS, PT_FLAG_NO_GRIDS, PT_FLAG_MEGAKERNEL = 1, 2, 4, 8
 TONEMAPS = {"REINHARD": 0, "FILMIC": 1, "ACES": 2}
 DEBUG_PLANES = ("normal", "albedo", "opacity", "metalness", "roughness", "emissive", "ior")
 
@@ -115,7 +115,9 @@ class Counters(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_prims", C.c_uint64), ("n_kd_nodes", C.c_uint64), ("n_kd_leaves", C.c_uint64),
                 ("n_leaf_refs", C.c_uint64), ("kd_depth", C.c_uint32), ("has_translucent", C.c_uint32),
-                ("kd_build_seconds", C.c_float), ("upload_seconds", C.c_float), ("device_bytes", C.c_uint64)]
+                ("kd_build_seconds", C.c_float), ("upload_seconds", C.c_float), ("device_bytes", C.c_uint64),
+                ("cam_grid_res", C.c_uint32), ("light_grids", C.c_uint32), ("grid_refs", C.c_uint64),
+                ("grid_build_seconds", C.c_float), ("_pad", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -38,6 +38,20 @@ struct DevLight {
     uint32_t tame;   // 1: every |colour component| < 1e30 (so colour / (4 pi d^2) stays finite for d > 1e-3)
 };
 
+// Origin grid (host/origin_grid.cpp, csrc/pt_grid.h): cube map of primitive lists around one point.
+//   cell_off  4 B / cell (+1): first reference of the cell; 6 faces x res x res cells
+//   refs      8 B / reference: (primitive id | sphere bit, bits(lower bound of the distance from the origin));
+//             the first n_global references are tested by every ray
+// res == 0: no grid (the casts use the KD-tree).
+struct DevGrid {
+    const uint32_t* cell_off;
+    const uint2* refs;
+    uint32_t res;
+    uint32_t n_global;
+    float half_res;
+    uint32_t _pad;
+};
+
 struct DevScene {
     const uint2* kd_nodes;
     const float4* leaf_prims;
@@ -59,6 +73,11 @@ struct DevScene {
     float cam_c0[3], cam_c1[3], cam_c2[3], cam_c3[3];
     float tan_half_fov;
     float background[3];
+    // origin grids: camera rays; shadow rays of point lights (light_grids[light], all or none: all_lights_gridded)
+    DevGrid cam_grid;
+    const DevGrid* light_grids;
+    uint32_t all_lights_gridded;
+    float light_grid_max_normal2;   // |surface normal|^2 up to which a shadow ray stays within the grids' margin
 };
 
 struct RenderParams {

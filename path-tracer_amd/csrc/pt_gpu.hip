@@ -1,12 +1,14 @@
 // libptgpu.so — HIP kernels and the C ABI of include/ptgpu.h (gfx950 only).
 //
-// Integrators (PT_INTEGRATOR)
+// Integrators
 //   wavefront (default)  pt_wavefront.h: k_wf_rng, then per bounce k_wf_trace (persistent),
 //                        k_wf_shade, k_wf_shadow (persistent, on a side stream beside the next trace);
-//                        k_accumulate adds the staged per-sample radiance in the reference's sample order
-//   persist              k_rng_blocks + k_render_persist: persistent lanes with path regeneration
-//   mega                 k_render<COUNT>: one lane per pixel, samples looped inside the lane
-//                        (renderer/mod.rs:105-130); kept for A/B runs and as a second implementation
+//                        k_accumulate adds the staged per-sample radiance in the reference's sample order.
+//                        pt_grid.h: camera rays and the shadow rays of point lights are cast through origin
+//                        grids (k_og_primary, k_og_shadow) instead of the KD-tree (PT_FLAG_NO_GRIDS: KD only)
+//   megakernel           k_render<COUNT> (PT_FLAG_MEGAKERNEL): one lane per pixel, samples looped inside the
+//                        lane (renderer/mod.rs:105-130), KD-tree only; the second, independent implementation
+//                        the parity tests cross-check the wavefront integrator with
 // Other kernels
 //   k_postprocess     Renderer::post_processing (mod.rs:335-353)
 //   k_assemble        scatter all-gathered packed tiles into a row-major image
@@ -30,6 +32,7 @@
 
 #include "pt_integrator.h"
 #include "pt_wavefront.h"
+#include "pt_grid.h"
 #include "pthost.h"
 
 // ------------------------------------------------------------------ errors
@@ -144,128 +147,6 @@ __global__ __launch_bounds__(256) void k_render(DevScene S, RenderParams P, cons
         atomicAdd(&ctr->tris_tested, (unsigned long long)lc.tris);
         atomicAdd(&ctr->shaded_hits, (unsigned long long)lc.shaded);
         atomicAdd(&ctr->rng_draws, (unsigned long long)draws);
-        atomicAdd(&ctr->restarts, (unsigned long long)lc.restarts);
-    }
-}
-
-// ------------------------------------------------------------------ persistent integrator
-// Work item w of a sample batch = one path sample:
-//     w = (block64 * batch + s_rel) * 64 + lane
-// block64 enumerates the 8x8 pixel blocks of this call's tiles, so 64 consecutive items are one
-// coherent 8x8 block of primary rays of the same sample, and consecutive groups are the next
-// samples of the same block (the CUs stay on one image region: better L2 locality per XCD).
-// First ChaCha12 block of every work item, word-major ([16][n_items]) so that the lanes of
-// a wavefront store 16 coalesced rows.  A fully converged kernel: ~700 integer ops per item.
-__global__ __launch_bounds__(256) void k_rng_blocks(RenderParams P, const uint32_t* __restrict__ tile_offsets,
-                                                    uint32_t n_items, uint32_t* __restrict__ blocks) {
-    uint32_t item = blockIdx.x * 256u + threadIdx.x;
-    if (item >= n_items) return;
-    ItemRef it = decode_item(P, tile_offsets, item);
-    if (!it.valid) return;
-    uint32_t w[16];
-    pt_chacha12_block((uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)P.samples, 0u, w);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) blocks[(size_t)i * n_items + item] = w[i];
-}
-
-// rng.gen::<f32>() number `idx` of work item `item`: the first block comes from k_rng_blocks,
-// later blocks (paths with more than 16 draws — rare) are regenerated in registers.
-__device__ __forceinline__ float item_draw(const uint32_t* __restrict__ blocks, uint32_t n_items, uint32_t item,
-                                           uint64_t seed, uint32_t idx) {
-    uint32_t word;
-    if (idx < 16u) {
-        word = blocks[(size_t)idx * n_items + item];
-    } else {
-        uint32_t w[16];
-        pt_chacha12_block(seed, idx >> 4, w);
-        word = w[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) word = (idx & 15u) == (uint32_t)i ? w[i] : word;
-    }
-    return (float)(word >> 8) * (1.0f / 16777216.0f);
-}
-
-// Persistent-threads integrator with path regeneration.  Every lane runs the loop
-//     fetch a work item if idle -> one bounce-loop iteration -> retire the sample when done
-// so the lanes of a wavefront sit in the same code (traversal / shading) on different samples
-// and bounces.  Work is fetched with one atomic per wavefront: ballot of the idle lanes,
-// popcount for the amount, mbcnt prefix for each lane's slot.  The sample's radiance goes to
-// staging[s_rel][pixel]; k_accumulate adds the samples in order afterwards, so the f32 sum per
-// pixel is the reference's `*pixel += color` sequence (mod.rs:130).
-template <bool COUNT>
-__global__ __launch_bounds__(256) void k_render_persist(DevScene S, RenderParams P,
-                                                        const uint32_t* __restrict__ tile_offsets,
-                                                        const uint32_t* __restrict__ rng_blocks, uint32_t n_items,
-                                                        float* __restrict__ staging, uint32_t* __restrict__ work_counter,
-                                                        DevCounters* __restrict__ ctr) {
-    const uint32_t lane = __lane_id();
-    PathState ps;
-    uint32_t item = 0, out_slot = 0, draw_idx = 0;
-    uint64_t seed = 0;
-    bool active = false, exhausted = false;
-    LocalCtr lc = {0, 0, 0, 0, 0, 0};
-    uint32_t n_samples = 0, n_draws = 0;
-    while (true) {
-        // ---- regeneration: idle lanes take the next items
-        bool need = !active && !exhausted;
-        unsigned long long m = __ballot(need);
-        if (m) {
-            uint32_t cnt = (uint32_t)__popcll(m);
-            int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(work_counter, cnt);
-            base = __shfl(base, leader);
-            if (need) {
-                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                uint32_t w = base + rank;
-                if (w >= n_items || base + rank < base) {
-                    exhausted = true;
-                } else {
-                    ItemRef it = decode_item(P, tile_offsets, w);
-                    if (it.valid) {
-                        item = w;
-                        seed = (uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)P.samples;
-                        out_slot = (it.sample - 1u - P.sample_begin) * P.n_local + it.out_index;
-                        float r1 = item_draw(rng_blocks, n_items, item, seed, 0u);
-                        float r2 = item_draw(rng_blocks, n_items, item, seed, 1u);
-                        draw_idx = 2;
-                        f3 o, d;
-                        primary_ray(S, it.x, it.y, P.width, P.height, r1, r2, o, d);
-                        path_begin(ps, o, d);
-                        active = true;
-                    }
-                }
-            }
-        }
-        if (!__any(active)) {
-            if (__all(exhausted)) break;
-            continue;
-        }
-        if (active) {
-            bool done = path_step<COUNT>(S, P.bounces, ps, lc, [&]() {
-                return item_draw(rng_blocks, n_items, item, seed, draw_idx++);
-            });
-            if (done) {
-                float* out = staging + (size_t)out_slot * 3;
-                out[0] = ps.color.x;
-                out[1] = ps.color.y;
-                out[2] = ps.color.z;
-                active = false;
-                if (COUNT) {
-                    n_samples++;
-                    n_draws += draw_idx;
-                }
-            }
-        }
-    }
-    if (COUNT) {
-        atomicAdd(&ctr->samples, (unsigned long long)n_samples);
-        atomicAdd(&ctr->segments, (unsigned long long)lc.segments);
-        atomicAdd(&ctr->shadow_rays, (unsigned long long)lc.shadow_rays);
-        atomicAdd(&ctr->nodes_visited, (unsigned long long)lc.nodes);
-        atomicAdd(&ctr->tris_tested, (unsigned long long)lc.tris);
-        atomicAdd(&ctr->shaded_hits, (unsigned long long)lc.shaded);
-        atomicAdd(&ctr->rng_draws, (unsigned long long)n_draws);
         atomicAdd(&ctr->restarts, (unsigned long long)lc.restarts);
     }
 }
@@ -562,16 +443,17 @@ struct pt_scene {
     pt_scene_info info{};
     mutable pt_timing timing{};
     mutable pt_counters counters{};
-    mutable DeviceBuffer accum_scratch, tile_table, counter_buf, staging_buf, rng_buf, work_counter;
+    mutable DeviceBuffer accum_scratch, tile_table, counter_buf, staging_buf;
     // The queues of the chunk of work items in flight.  The shadow casts of bounce b run on a side stream
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
-        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws;
+        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid;
         hipStream_t side = nullptr, side_rng = nullptr;
         hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr;
     };
     mutable WfPipe pipe;
-    mutable int persist_blocks = 0, trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
+    mutable int trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
+    mutable uint32_t wf_cap_ok = 0;   // largest queue capacity the device provided so far (0: not tried)
     mutable std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> tile_key{0, 0, 0, 0, 0, 0};
     mutable std::vector<hipEvent_t> events;
 
@@ -779,6 +661,59 @@ void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
     D.tan_half_fov = tanf(d.camera.fov / 2.f);  // Rad::tan(fov / 2.) (mod.rs:116,120)
     memcpy(D.background, d.background, 12);
 
+    // ---- origin grids (host/origin_grid.cpp, csrc/pt_grid.h): camera rays, shadow rays of point lights
+    {
+        auto t_grid = std::chrono::steady_clock::now();
+        static const bool grids_on = [] {
+            const char* e = getenv("PT_OG");
+            return !(e && *e && atoi(e) == 0);
+        }();
+        auto upload_grid = [&](pth_origin_grid& g, DevGrid& out) {
+            std::unique_ptr<pth_origin_grid, void (*)(pth_origin_grid*)> guard(&g, pth_origin_grid_free);
+            memset(&out, 0, sizeof out);
+            if (!g.enabled) return;
+            out.cell_off = s.upload(g.cell_off, g.n_cells + 1);
+            out.refs = (const uint2*)s.upload(g.refs, std::max<uint64_t>(1, g.n_refs));
+            out.res = g.res;
+            out.n_global = g.n_global;
+            out.half_res = 0.5f * (float)g.res;
+            s.info.grid_refs += g.n_refs;
+        };
+        memset(&D.cam_grid, 0, sizeof D.cam_grid);
+        // longest camera-ray direction: |M dir| <= ||M||_F for the unit vector dir (mod.rs:122-123)
+        double fro = 0;
+        for (int k = 0; k < 3; ++k)
+            for (int r = 0; r < 3; ++r) fro += (double)M[4 * k + r] * M[4 * k + r];
+        fro = std::sqrt(fro);
+        if (grids_on && n_prims > 0 && fro > 0 && fro < 64.0) {
+            pth_origin_grid g;
+            if (pth_origin_grid_build(&d, M + 12, 0, 0.f, (float)(fro * 1.001), &g) != PT_OK)
+                fail(PT_ERR_INVALID, "origin grid (camera): %s", pth_last_error());
+            upload_grid(g, D.cam_grid);
+            s.info.cam_grid_res = D.cam_grid.res;
+        }
+        // lights: the shadow queue is consumed by ONE kernel, so the grids serve the shadow rays only when every
+        // light is a point light with a grid.  A shadow ray starts n * 1e-5 off the line through the light
+        // (mod.rs:291,319): the grids' margin covers |n| <= 1.5, longer normals take the KD-tree per surface.
+        std::vector<DevGrid> lgrids(d.n_lights);
+        bool all = grids_on && d.n_lights > 0 && n_prims > 0;
+        for (uint32_t i = 0; i < d.n_lights && all; ++i)
+            if (d.lights[i].kind != PT_LIGHT_POINT) all = false;
+        const float max_normal = 1.5f;
+        for (uint32_t i = 0; i < d.n_lights && all; ++i) {
+            pth_origin_grid g;
+            if (pth_origin_grid_build(&d, d.lights[i].vec, 0, 1.05e-5f * max_normal, 1.001f, &g) != PT_OK)
+                fail(PT_ERR_INVALID, "origin grid (light %u): %s", i, pth_last_error());
+            upload_grid(g, lgrids[i]);
+            if (!lgrids[i].res) all = false;
+        }
+        D.light_grids = s.upload(lgrids.data(), lgrids.size());
+        D.all_lights_gridded = all ? 1u : 0u;
+        D.light_grid_max_normal2 = max_normal * max_normal;
+        s.info.light_grids = all ? d.n_lights : 0u;
+        s.info.grid_build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_grid).count();
+    }
+
     s.info.n_prims = n_prims;
     s.info.n_kd_nodes = kd.n_nodes;
     s.info.n_kd_leaves = kd.n_leaves;
@@ -848,14 +783,12 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     pt_fastdiv_make(o.tile_w >> 3, P.div_tile_cols);
     pt_fastdiv_make(tm.tiles_x, P.div_tiles_x);
 
-    // ---- integrator selection: wavefront (default), or for A/B measurements the fused
-    // persistent kernel (PT_INTEGRATOR=persist) / the one-lane-per-pixel megakernel (=mega)
-    static const int mode = [] {
-        const char* e = getenv("PT_INTEGRATOR");
-        if (e && !strcmp(e, "mega")) return 0;
-        if (e && !strcmp(e, "persist")) return 1;
-        return 2;
-    }();
+    // ---- integrator selection: wavefront (default, mode 2), or the one-lane-per-pixel megakernel (mode 0)
+    const int mode = (o.flags & PT_FLAG_MEGAKERNEL) ? 0 : 2;
+    // the 16-bit draw index / bounce fields of the queue records, the per-bounce counter table
+    if (p.bounces > 4096u) fail(PT_ERR_INVALID, "profile.bounces %u is out of range (at most 4096)", p.bounces);
+    const bool use_cam_grid = !(o.flags & PT_FLAG_NO_GRIDS) && s.dev.cam_grid.res != 0;
+    const bool use_light_grids = !(o.flags & PT_FLAG_NO_GRIDS) && s.dev.all_lights_gridded != 0;
     const uint32_t blocks64 = tm.n_local_tiles * (o.tile_w / 8u) * (o.tile_h / 8u);
     // staging budget (radiance 12 B + RNG block 64 B per work item [+ queues]); default 32 GiB of 288 GB
     static const uint64_t budget = [] {
@@ -893,27 +826,21 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     uint32_t batch = o.sample_batch ? o.sample_batch : p.samples;
     const bool alpha = s.dev.has_translucent != 0;
     if (mode >= 1) {
-        uint64_t per_sample = (mode == 1 ? (uint64_t)blocks64 * 64u * 64u : 0) + tm.n_local * 12u;
+        uint64_t per_sample = tm.n_local * 12u;
         uint64_t max_batch = std::max<uint64_t>(1, budget / std::max<uint64_t>(1, per_sample));
         max_batch = std::min<uint64_t>(max_batch, 0x7fffffffull / ((uint64_t)blocks64 * 64u));
         if (max_batch == 0) fail(PT_ERR_UNSUPPORTED, "image too large for one sample batch");
         batch = (uint32_t)std::min<uint64_t>(batch, max_batch);
         s.staging_buf.ensure((size_t)batch * tm.n_local * 12);
-        s.work_counter.ensure(256);
-    }
-    if (mode == 1) {
-        if (s.persist_blocks == 0) {
-            int per_cu = 0;
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_persist<false>, 256, 0));
-            s.persist_blocks = std::max(1, per_cu) * std::max(1, s.n_cu);
-        }
-        s.rng_buf.ensure((size_t)batch * blocks64 * 64u * 64u);
     }
     uint32_t cap = 0;
     if (mode == 2) {
         uint64_t items_per_batch = (uint64_t)blocks64 * 64u * batch;
         // chunks are whole 64-item groups
         cap = (uint32_t)std::min<uint64_t>(items_per_batch, std::max<uint32_t>(64u, wf_cap & ~63u));
+        // a device that once could not provide the full-size queues is not asked again on every frame (each
+        // failed attempt costs several synchronising hipMalloc / hipFree calls)
+        if (s.wf_cap_ok) cap = std::min(cap, s.wf_cap_ok);
         if (s.trace_blocks == 0) {
             int a = 0, b = 0, c = 0, d = 0;
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_wf_trace<false, false, false>, WF_THREADS, 0));
@@ -944,9 +871,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       w.hits.try_ensure((size_t)cap * 16u) && w.shadow.try_ensure((size_t)cap * 64u) &&
                       w.contrib.try_ensure((size_t)cap * 16u * lights) && w.rng[0].try_ensure((size_t)cap * 32u) &&
                       (!(multi_chunk && wf_overlap) || w.rng[1].try_ensure((size_t)cap * 32u)) &&
-                      (!alpha || w.draws.try_ensure((size_t)cap * 4u));   // RNG draw index of the alpha walk
-            if (ok) break;
-            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1], &w.draws})
+                      (!alpha || w.draws.try_ensure((size_t)cap * 4u)) &&   // RNG draw index of the alpha walk
+                      (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u));   // surfaces left to the KD-tree
+            if (ok) {
+                if (multi_chunk) s.wf_cap_ok = cap;   // (a frame that fits in one chunk says nothing about larger ones)
+                break;
+            }
+            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1], &w.draws, &w.offgrid})
                 b->release();
             if (cap <= (1u << 20))
                 fail(PT_ERR_DEVICE, "out of device memory: the path queues need %zu bytes for %u work items",
@@ -993,26 +924,6 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum, gctr);
             else
                 hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum, gctr);
-            HIP_CHECK(hipGetLastError());
-            stage_end();
-            ++launches;
-        } else if (mode == 1) {
-            uint32_t n_items = blocks64 * 64u * nb;
-            stage_begin(0);
-            hipLaunchKernelGGL(k_rng_blocks, dim3((n_items + 255u) / 256u), dim3(256), 0, stream, P, d_tiles, n_items,
-                               (uint32_t*)s.rng_buf.p);
-            HIP_CHECK(hipGetLastError());
-            stage_end();
-            HIP_CHECK(hipMemsetAsync(s.work_counter.p, 0, 4, stream));
-            stage_begin(5);
-            if (counting)
-                hipLaunchKernelGGL(k_render_persist<true>, dim3(s.persist_blocks), dim3(256), 0, stream, s.dev, P, d_tiles,
-                                   (const uint32_t*)s.rng_buf.p, n_items, (float*)s.staging_buf.p,
-                                   (uint32_t*)s.work_counter.p, gctr);
-            else
-                hipLaunchKernelGGL(k_render_persist<false>, dim3(s.persist_blocks), dim3(256), 0, stream, s.dev, P, d_tiles,
-                                   (const uint32_t*)s.rng_buf.p, n_items, (float*)s.staging_buf.p,
-                                   (uint32_t*)s.work_counter.p, gctr);
             HIP_CHECK(hipGetLastError());
             stage_end();
             ++launches;
@@ -1091,8 +1002,25 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         HIP_CHECK(hipGetLastError());                                                                                    \
     } while (0)
                     stage_begin(1);
-                    PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
-                                  (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, wctr, gctr);
+                    if (prim && use_cam_grid) {   // camera rays: one grid lookup instead of a KD walk (pt_grid.h)
+                        const dim3 g((W.n_items + 255u) / 256u);
+                        if (alpha && counting)
+                            hipLaunchKernelGGL((k_og_primary<true, true>), g, dim3(256), 0, st_main, s.dev, W, d_tiles,
+                                               (uint4*)pipe.hits.p, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, gctr);
+                        else if (alpha)
+                            hipLaunchKernelGGL((k_og_primary<true, false>), g, dim3(256), 0, st_main, s.dev, W, d_tiles,
+                                               (uint4*)pipe.hits.p, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, gctr);
+                        else if (counting)
+                            hipLaunchKernelGGL((k_og_primary<false, true>), g, dim3(256), 0, st_main, s.dev, W, d_tiles,
+                                               (uint4*)pipe.hits.p, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, gctr);
+                        else
+                            hipLaunchKernelGGL((k_og_primary<false, false>), g, dim3(256), 0, st_main, s.dev, W, d_tiles,
+                                               (uint4*)pipe.hits.p, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, gctr);
+                        HIP_CHECK(hipGetLastError());
+                    } else {
+                        PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
+                                      (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, wctr, gctr);
+                    }
                     stage_end();
                     ++launches;
                     // shade(b) reads the colours shadow(b-1) patched and refills the shadow queue it consumed
@@ -1113,8 +1041,32 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     WfParams Ws = W;
                     if (wf_refill_shadow) Ws.refill_min = std::min(64u, wf_refill_shadow);
                     if (wf_walk_shadow) Ws.walk_steps = wf_walk_shadow;
-                    PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, s.dev, Ws, (const float4*)pipe.shadow.p,
-                                 (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, wctr, gctr);
+                    if (use_light_grids) {   // every light a point light with a grid (pt_grid.h): plain grid-stride kernel
+                        const dim3 g((uint32_t)s.n_cu * 16u);
+#define PT_LAUNCH_OGS(A, C)                                                                                      \
+    hipLaunchKernelGGL((k_og_shadow<A, C>), g, dim3(256), 0, st_shadow, s.dev, Ws, (const float4*)pipe.shadow.p, \
+                       (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, (uint32_t*)pipe.offgrid.p, wctr, gctr)
+                        if (alpha && counting) PT_LAUNCH_OGS(true, true);
+                        else if (alpha) PT_LAUNCH_OGS(true, false);
+                        else if (counting) PT_LAUNCH_OGS(false, true);
+                        else PT_LAUNCH_OGS(false, false);
+#undef PT_LAUNCH_OGS
+                        HIP_CHECK(hipGetLastError());
+                        // surfaces with a normal too long for the grids' margin (normally none: the launch finds
+                        // an empty list and returns)
+                        if (counting)
+                            hipLaunchKernelGGL((k_og_shadow_offgrid<true>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, s.dev, Ws,
+                                               (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out,
+                                               (float*)s.staging_buf.p, (const uint32_t*)pipe.offgrid.p, wctr, gctr);
+                        else
+                            hipLaunchKernelGGL((k_og_shadow_offgrid<false>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, s.dev, Ws,
+                                               (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out,
+                                               (float*)s.staging_buf.p, (const uint32_t*)pipe.offgrid.p, wctr, gctr);
+                        HIP_CHECK(hipGetLastError());
+                    } else {
+                        PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, s.dev, Ws, (const float4*)pipe.shadow.p,
+                                     (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, wctr, gctr);
+                    }
                     stage_end();
                     stage_stream = st_main;
                     if (st_shadow != st_main) HIP_CHECK(hipEventRecord(pipe.ev_shadow, st_shadow));

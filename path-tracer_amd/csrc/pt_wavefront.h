@@ -77,6 +77,7 @@ struct WfCounters {  // one set per bounce level, zeroed once per chunk
     uint32_t shadow_count;   // records in the shadow queue of bounce b
     uint32_t trace_work;     // dynamic fetch cursors
     uint32_t shadow_work;
+    uint32_t offgrid_count;  // shadow records k_og_shadow left to k_og_shadow_offgrid (pt_grid.h)
 };
 
 #define WF_FLAG_TERMINATED 1u

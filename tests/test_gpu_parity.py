@@ -282,6 +282,65 @@ def test_translucent_generated_scene_is_bit_identical(pta, oracle):
     assert c["restarts"] > 0
 
 
+# ---------------------------------------------------------------------------------------------
+# Three ways to the same bits: origin grids for camera / point-light shadow rays (default), the KD-tree
+# for every ray (PT_FLAG_NO_GRIDS), and the one-lane-per-pixel megakernel (PT_FLAG_MEGAKERNEL, KD-tree).
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", SCENES)
+def test_grid_kd_and_megakernel_paths_agree(pta, scene_cache, gpu_scene_cache, name):
+    g = gpu_scene_cache(name)
+    info = g.info().as_dict()
+    assert info["cam_grid_res"] > 0          # every reference scene gets a camera grid
+    point_only = all(scene_cache(name).desc.contents.lights[i].kind == pta.PT_LIGHT_POINT
+                     for i in range(scene_cache(name).n_lights))
+    assert (info["light_grids"] > 0) == (point_only and scene_cache(name).n_lights > 0)
+    prof = pta.Profile.make(200, 150, 6, 5)
+    rgb, acc = g.render(prof)
+    rgb_kd, acc_kd = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_NO_GRIDS))
+    rgb_mk, acc_mk = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_MEGAKERNEL))
+    assert np.array_equal(bits(acc), bits(acc_kd)) and np.array_equal(rgb, rgb_kd)
+    assert np.array_equal(bits(acc), bits(acc_mk)) and np.array_equal(rgb, rgb_mk)
+    # the event counters of the two wavefront paths agree as well (they count path events, not traversal work)
+    g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS))
+    c1 = g.counters().as_dict()
+    g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS | pta.PT_FLAG_NO_GRIDS))
+    c2 = g.counters().as_dict()
+    for k in ("samples", "segments", "shadow_rays", "shaded_hits", "rng_draws", "shadow_skipped"):
+        assert c1[k] == c2[k], (k, c1[k], c2[k])
+
+
+def test_generated_scene_grid_and_kd_paths_agree(pta):
+    for flags in (0, 1):   # opaque, translucent shells
+        scene = pta.HostScene.generate_ps5(30000, seed=0, flags=flags)
+        g = pta.GpuScene(scene)
+        assert g.info().cam_grid_res > 0 and g.info().light_grids == 1
+        prof = pta.Profile.make(320, 180, 8, 5, "ACES")
+        rgb, acc = g.render(prof)
+        rgb_kd, acc_kd = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_NO_GRIDS))
+        assert np.array_equal(bits(acc), bits(acc_kd)) and np.array_equal(rgb, rgb_kd)
+
+
+def test_long_normals_leave_the_light_grid(pta, oracle, tmp_path):
+    """A shadow ray starts normal * 1e-5 off the line through the light (mod.rs:319); vertex normals are scene data of
+    any length.  Surfaces whose interpolated normal is longer than the grids' margin allows are cast on the KD-tree
+    (k_og_shadow_offgrid): same bits as the oracle either way."""
+    def tri(a, b, c, n):
+        return [{"position": p, "normal": n, "tex_coords": [0, 0]} for p in (a, b, c)]
+    mat = {"albedo": {"factor": [0.8, 0.7, 0.6]}, "roughness": {"factor": 0.4}}
+    floor = [tri([-3, -1, -3], [3, -1, -3], [3, -1, 3], [0, 4, 0]), tri([-3, -1, -3], [3, -1, 3], [-3, -1, 3], [0, 0.5, 0])]
+    blocker = [tri([-0.5, 0.2, -0.5], [0.5, 0.2, -0.5], [0, 0.2, 0.6], [0, 2.5, 0])]
+    models = [{"type": "Mesh", "triangles": floor, "material": mat}, {"type": "Mesh", "triangles": blocker, "material": mat},
+              {"type": "Sphere", "radius": 0.4, "center": [1.2, -0.5, 0.3], "material": mat}]
+    lights = [{"type": "Point", "position": [0.3, 3, 0.5], "color": [60, 60, 60], "size": 0.1},
+              {"type": "Point", "position": [-2, 1, 2], "color": [20, 30, 40], "size": 0.1}]
+    scene = pta.HostScene.load_isf(_write_isf(tmp_path, "long_normals", models, lights))
+    g = pta.GpuScene(scene)
+    assert g.info().light_grids == 2
+    prof = pta.Profile.make(160, 120, 6, 3)
+    ok, u8_ok, exact, same = compare_render(pta, oracle, scene, g, prof)
+    assert exact == 1.0 and same
+
+
 def _write_isf(tmp_path, name, models, lights, background=(0.25, 0.5, 1.0)):
     import json
     cam = {"transform": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 4, 1]], "fov": 0.8, "zfar": 100.0, "znear": 0.1}
