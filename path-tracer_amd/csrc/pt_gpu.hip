@@ -32,7 +32,7 @@
 
 #include "pt_integrator.h"
 #include "pt_wavefront.h"
-#include "pt_grid.h"
+#include "pt_grid_kernels.h"
 #include "pthost.h"
 
 // ------------------------------------------------------------------ errors
@@ -935,7 +935,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             // opaque scenes, several chunks: the RNG planes of chunk c+1 are produced on their own stream while
             // chunk c runs its bounces (k_wf_rng is pure integer ALU work; the traversal kernels leave ~40 % of
             // the issue slots idle and end in a drain phase)
-            const bool rng_ahead = wf_overlap && total_items > cap && pipe.side_rng != nullptr;
+            // opaque scenes with both kinds of grid: the bounce-0 kernel computes the ChaCha block itself (GRID 3)
+            static const bool fuse_rng = [] {
+                const char* e = getenv("PT_OG_FUSE_RNG");
+                return e && *e ? atoi(e) != 0 : true;
+            }();
+            const bool fused_rng = fuse_rng && use_cam_grid && use_light_grids && !alpha;
+            const bool rng_ahead = !fused_rng && wf_overlap && total_items > cap && pipe.side_rng != nullptr;
             uint32_t chunk_no = 0;
             for (uint32_t base = 0; base < total_items; base += cap, ++chunk_no) {
                 WfParams W{};
@@ -950,7 +956,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 HIP_CHECK(hipMemsetAsync(wctr, 0, sizeof(WfCounters) * (p.bounces + 3), st_main));
                 // bounce 0 derives the camera rays in place from the staged screen positions (no queue[0])
                 const bool fused_primary = true;
-                if (!rng_ahead || chunk_no == 0) {
+                if (fused_rng) {
+                    // (no k_wf_rng launch)
+                } else if (!rng_ahead || chunk_no == 0) {
                     stage_begin(0);
                     hipLaunchKernelGGL(k_wf_rng, dim3((W.n_items + 255u) / 256u), dim3(256), 0, st_main, s.dev, W, d_tiles,
                                        rng_planes);
@@ -980,6 +988,14 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     float4* q_in = (float4*)pipe.queue[b & 1].p;
                     float4* q_out = (float4*)pipe.queue[(b + 1) & 1].p;
                     const bool prim = fused_primary && b == 0;
+                    // origin grids (pt_grid.h): 2 = camera cast + shadow casts inside the shade kernel (bounce 0, both
+                    // kinds of grid), 1 = shadow casts inside the shade kernel, 0 = none
+                    // (bounces >= 1 keep the shade kernel lean and cast their shadow rays in k_og_shadow: measured faster)
+                    static const int inline_later = [] {
+                        const char* e = getenv("PT_OG_INLINE_ALL");
+                        return e && *e ? atoi(e) : 0;
+                    }();
+                    const int grid_mode = use_light_grids ? ((prim && use_cam_grid) ? (fused_rng ? 3 : 2) : (inline_later ? 1 : 0)) : 0;
 #define PT_LAUNCH_ACP(kernel, grid, threads, ...)                                                                                      \
     do {                                                                                                                               \
         if (prim && alpha && counting)                                                                                                  \
@@ -1001,36 +1017,61 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         else hipLaunchKernelGGL((kernel<false, false>), dim3(grid), dim3(WF_THREADS), 0, st_shadow, __VA_ARGS__);                 \
         HIP_CHECK(hipGetLastError());                                                                                    \
     } while (0)
-                    stage_begin(1);
-                    if (prim && use_cam_grid) {   // camera rays: one grid lookup instead of a KD walk (pt_grid.h)
-                        const dim3 g((W.n_items + 255u) / 256u);
-                        if (alpha && counting)
-                            hipLaunchKernelGGL((k_og_primary<true, true>), g, dim3(256), 0, st_main, s.dev, W, d_tiles,
-                                               (uint4*)pipe.hits.p, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, gctr);
-                        else if (alpha)
-                            hipLaunchKernelGGL((k_og_primary<true, false>), g, dim3(256), 0, st_main, s.dev, W, d_tiles,
-                                               (uint4*)pipe.hits.p, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, gctr);
-                        else if (counting)
-                            hipLaunchKernelGGL((k_og_primary<false, true>), g, dim3(256), 0, st_main, s.dev, W, d_tiles,
-                                               (uint4*)pipe.hits.p, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, gctr);
-                        else
-                            hipLaunchKernelGGL((k_og_primary<false, false>), g, dim3(256), 0, st_main, s.dev, W, d_tiles,
-                                               (uint4*)pipe.hits.p, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, gctr);
-                        HIP_CHECK(hipGetLastError());
-                    } else {
-                        PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
-                                      (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, wctr, gctr);
+// k_wf_shade<ALPHA, COUNT, PRIMARY, GRID>
+#define PT_SHADE_ARGS                                                                                                         \
+    s.dev, W, d_tiles, (const float4*)q_in, (const uint4*)pipe.hits.p, (const uint4*)rng_planes, (const uint32_t*)pipe.draws.p, \
+        q_out, (float4*)pipe.shadow.p, (float4*)pipe.contrib.p, (float*)s.staging_buf.p, wctr, gctr
+#define PT_LAUNCH_SHADE(A, C, P, G)                                                                                    \
+    hipLaunchKernelGGL((k_wf_shade<A, C, P, G>), dim3((uint32_t)(s.n_cu * 4 * (1024 / WF_SHADE_THREADS))),             \
+                       dim3(WF_SHADE_THREADS), 0, st_main, PT_SHADE_ARGS)
+#define PT_LAUNCH_SHADE_G(G)                                                   \
+    do {                                                                       \
+        if (prim && alpha && counting) PT_LAUNCH_SHADE(true, true, true, G);   \
+        else if (prim && alpha) PT_LAUNCH_SHADE(true, false, true, G);         \
+        else if (prim && counting) PT_LAUNCH_SHADE(false, true, true, G);      \
+        else if (prim) PT_LAUNCH_SHADE(false, false, true, G);                 \
+        else if (alpha && counting) PT_LAUNCH_SHADE(true, true, false, G);     \
+        else if (alpha) PT_LAUNCH_SHADE(true, false, false, G);                \
+        else if (counting) PT_LAUNCH_SHADE(false, true, false, G);             \
+        else PT_LAUNCH_SHADE(false, false, false, G);                          \
+    } while (0)
+                    if (grid_mode < 2) {   // (grid_mode >= 2: k_wf_shade casts the camera rays itself)
+                        stage_begin(1);
+                        if (prim && use_cam_grid) {   // camera rays: one grid lookup instead of a KD walk (pt_grid_kernels.h)
+                            const dim3 g((W.n_items + 255u) / 256u);
+#define PT_LAUNCH_OGP(A, C)                                                                                                   \
+    hipLaunchKernelGGL((k_og_primary<A, C>), g, dim3(256), 0, st_main, s.dev, W, d_tiles, (uint4*)pipe.hits.p, \
+                       (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, gctr)
+                            if (alpha && counting) PT_LAUNCH_OGP(true, true);
+                            else if (alpha) PT_LAUNCH_OGP(true, false);
+                            else if (counting) PT_LAUNCH_OGP(false, true);
+                            else PT_LAUNCH_OGP(false, false);
+#undef PT_LAUNCH_OGP
+                            HIP_CHECK(hipGetLastError());
+                        } else {
+                            PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
+                                          (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, wctr, gctr);
+                        }
+                        stage_end();
+                        ++launches;
                     }
-                    stage_end();
-                    ++launches;
                     // shade(b) reads the colours shadow(b-1) patched and refills the shadow queue it consumed
                     if (st_shadow != st_main && b > 0) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
                     stage_begin(2);
-                    PT_LAUNCH_ACP(k_wf_shade, (uint32_t)(s.n_cu * 4 * (1024 / WF_SHADE_THREADS)), WF_SHADE_THREADS, s.dev, W, d_tiles, (const float4*)q_in,
-                                  (const uint4*)pipe.hits.p, (const uint4*)rng_planes, (const uint32_t*)pipe.draws.p, q_out,
-                                  (float4*)pipe.shadow.p,
-                                  (float4*)pipe.contrib.p,
-                                  (float*)s.staging_buf.p, wctr, gctr);
+                    if (grid_mode == 3) {
+                        if (counting) PT_LAUNCH_SHADE(false, true, true, 3);
+                        else PT_LAUNCH_SHADE(false, false, true, 3);
+                    } else if (grid_mode == 2) {
+                        if (alpha && counting) PT_LAUNCH_SHADE(true, true, true, 2);
+                        else if (alpha) PT_LAUNCH_SHADE(true, false, true, 2);
+                        else if (counting) PT_LAUNCH_SHADE(false, true, true, 2);
+                        else PT_LAUNCH_SHADE(false, false, true, 2);
+                    } else if (grid_mode == 1) {
+                        PT_LAUNCH_SHADE_G(1);
+                    } else {
+                        PT_LAUNCH_SHADE_G(0);
+                    }
+                    HIP_CHECK(hipGetLastError());
                     stage_end();
                     if (st_shadow != st_main) {
                         HIP_CHECK(hipEventRecord(pipe.ev_shade, st_main));
@@ -1041,27 +1082,24 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     WfParams Ws = W;
                     if (wf_refill_shadow) Ws.refill_min = std::min(64u, wf_refill_shadow);
                     if (wf_walk_shadow) Ws.walk_steps = wf_walk_shadow;
-                    if (use_light_grids) {   // every light a point light with a grid (pt_grid.h): plain grid-stride kernel
-                        const dim3 g((uint32_t)s.n_cu * 16u);
-#define PT_LAUNCH_OGS(A, C)                                                                                      \
-    hipLaunchKernelGGL((k_og_shadow<A, C>), g, dim3(256), 0, st_shadow, s.dev, Ws, (const float4*)pipe.shadow.p, \
-                       (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, (uint32_t*)pipe.offgrid.p, wctr, gctr)
-                        if (alpha && counting) PT_LAUNCH_OGS(true, true);
-                        else if (alpha) PT_LAUNCH_OGS(true, false);
-                        else if (counting) PT_LAUNCH_OGS(false, true);
-                        else PT_LAUNCH_OGS(false, false);
-#undef PT_LAUNCH_OGS
+#define PT_OGS_ARGS                                                                                                    \
+    s.dev, Ws, (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, \
+        (uint32_t*)pipe.offgrid.p, wctr, gctr
+                    if (grid_mode != 0) {
+                        // what is left in the shadow queue: surfaces with a normal too long for the grids' margin
+                        // (normally none: the launch finds an empty queue and returns)
+                        if (counting) hipLaunchKernelGGL((k_og_shadow_offgrid<true, false>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, PT_OGS_ARGS);
+                        else hipLaunchKernelGGL((k_og_shadow_offgrid<false, false>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, PT_OGS_ARGS);
                         HIP_CHECK(hipGetLastError());
-                        // surfaces with a normal too long for the grids' margin (normally none: the launch finds
-                        // an empty list and returns)
-                        if (counting)
-                            hipLaunchKernelGGL((k_og_shadow_offgrid<true>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, s.dev, Ws,
-                                               (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out,
-                                               (float*)s.staging_buf.p, (const uint32_t*)pipe.offgrid.p, wctr, gctr);
-                        else
-                            hipLaunchKernelGGL((k_og_shadow_offgrid<false>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, s.dev, Ws,
-                                               (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out,
-                                               (float*)s.staging_buf.p, (const uint32_t*)pipe.offgrid.p, wctr, gctr);
+                    } else if (use_light_grids) {   // every light a point light with a grid: plain grid-stride kernel
+                        const dim3 g((uint32_t)s.n_cu * 16u);
+                        if (alpha && counting) hipLaunchKernelGGL((k_og_shadow<true, true>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);
+                        else if (alpha) hipLaunchKernelGGL((k_og_shadow<true, false>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);
+                        else if (counting) hipLaunchKernelGGL((k_og_shadow<false, true>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);
+                        else hipLaunchKernelGGL((k_og_shadow<false, false>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);
+                        HIP_CHECK(hipGetLastError());
+                        if (counting) hipLaunchKernelGGL((k_og_shadow_offgrid<true, true>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, PT_OGS_ARGS);
+                        else hipLaunchKernelGGL((k_og_shadow_offgrid<false, true>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, PT_OGS_ARGS);
                         HIP_CHECK(hipGetLastError());
                     } else {
                         PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, s.dev, Ws, (const float4*)pipe.shadow.p,
@@ -1070,8 +1108,12 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     stage_end();
                     stage_stream = st_main;
                     if (st_shadow != st_main) HIP_CHECK(hipEventRecord(pipe.ev_shadow, st_shadow));
+#undef PT_OGS_ARGS
 #undef PT_LAUNCH_ACP
 #undef PT_LAUNCH_AC
+#undef PT_LAUNCH_SHADE_G
+#undef PT_LAUNCH_SHADE
+#undef PT_SHADE_ARGS
                 }
                 // the next chunk clears the counters and reuses the queues, accumulate reads the staging area:
                 // join the side stream

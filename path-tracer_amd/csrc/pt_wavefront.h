@@ -24,6 +24,7 @@
 // entry (same ballot/popcount scheme), so long traversals do not hold 63 idle lanes.
 #pragma once
 #include "pt_integrator.h"
+#include "pt_grid.h"
 
 // Work item -> pixel / sample (see the item numbering in pt_gpu.hip).
 struct ItemRef {
@@ -77,7 +78,7 @@ struct WfCounters {  // one set per bounce level, zeroed once per chunk
     uint32_t shadow_count;   // records in the shadow queue of bounce b
     uint32_t trace_work;     // dynamic fetch cursors
     uint32_t shadow_work;
-    uint32_t offgrid_count;  // shadow records k_og_shadow left to k_og_shadow_offgrid (pt_grid.h)
+    uint32_t offgrid_count;  // shadow records k_og_shadow left to k_og_shadow_offgrid (pt_grid_kernels.h)
 };
 
 #define WF_FLAG_TERMINATED 1u
@@ -708,20 +709,36 @@ PT_D bool wf_light_is_moot(const DevLight& L, f3 term, f3 surface_pos) {
 // atomics per microsecond and word).  Register budget WF_SHADE_WAVES in every case.
 #define WF_SHADE_THREADS 256
 #endif
-template <bool ALPHA, bool COUNT, bool PRIMARY>
 #ifndef WF_SHADE_WAVES
 #define WF_SHADE_WAVES 4      // waves per SIMD the kernel is compiled for (register budget 512 / 4)
 #endif
-__global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(DevScene S, WfParams W,
+#ifndef WF_SHADE_GRID_WAVES
+#define WF_SHADE_GRID_WAVES 4 // the same for the variants that cast through origin grids inline
+#endif
+// GRID (origin grids, pt_grid.h): 0 - none: direct light goes through the shadow queue and k_wf_shadow / k_og_shadow;
+// 1 - every light is a point light with a grid: get_light_info (mod.rs:281-333) is evaluated HERE, light after
+//     light, so a surface costs no shadow record, no contrib entries and no colour patch (190 B of queue traffic
+//     per shaded hit); only surfaces whose normal is too long for the grids' margin still take the queue;
+// 2 - (bounce 0) 1 + the camera ray is cast HERE through the camera grid: no hits[] round trip, and the 44 % of
+//     the samples that leave into the background never reach a second kernel;
+// 3 - (bounce 0, opaque scenes) 2 + the item's ChaCha12 block is computed HERE instead of by k_wf_rng: the ~800
+//     integer instructions per item run underneath the memory latency of the casts, and only the paths that
+//     go on write the words of bounces 1 and 2 (plane 1 of the RNG planes).
+template <bool ALPHA, bool COUNT, bool PRIMARY, int GRID>
+__global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_SHADE_WAVES) void k_wf_shade(DevScene S, WfParams W,
                                                   const uint32_t* __restrict__ tile_offsets,
                                                   const float4* __restrict__ queue_in, const uint4* __restrict__ hits,
-                                                  const uint4* __restrict__ rng_planes,
+                                                  const uint4* rng_planes,
                                                   const uint32_t* __restrict__ draws,
                                                   float4* __restrict__ queue_out, float4* __restrict__ shadow_q,
                                                   float4* __restrict__ contrib, float* __restrict__ staging,
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
+    uint4* rng_planes_out = const_cast<uint4*>(rng_planes);   // GRID == 3 writes plane 1 (nobody reads it before bounce 1)
+    static_assert(GRID < 2 || PRIMARY, "the camera grid serves bounce 0");
+    static_assert(GRID != 3 || !ALPHA, "translucent scenes stage their RNG words (the alpha walk draws)");
     const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
     uint32_t n_draws = 0, n_new = 0, n_moot = 0;
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};   // (GRID: casts made here)
     __shared__ uint32_t sh_cnt[2][WF_SHADE_THREADS / 64];
     __shared__ uint32_t sh_base[2];
     const uint32_t wave = threadIdx.x >> 6;
@@ -736,6 +753,8 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
     bool hit = false;
     WfRng rng;
     rng.block = 0xffffffffu;
+    float r1_0 = 0.f, r2_0 = 0.f;                       // GRID == 3: draws 2 and 3 of the item
+    uint4 later_words = make_uint4(0u, 0u, 0u, 0u);     //            words 4-7 (bounces 1 and 2)
     if (PRIMARY && live) {  // entry i is work item i: the initial path state, built in place
         ItemRef it = decode_item(W.P, tile_offsets, W.item_base + i);
         if (!it.valid) {
@@ -743,12 +762,53 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
         } else {
             thr = mk3(1.f, 1.f, 1.f);
             color = mk3(0.f, 0.f, 0.f);
-            draw = ALPHA ? draws[i] : 2u;   // 2 = the pixel jitter (+ the draws of the alpha walk)
             out_slot = (it.sample - 1u - W.P.sample_begin) * W.P.n_local + it.out_index;
-            hit = unpack_hit(hits[i], h);
-            if (hit) {  // (a missed cast only adds the background: no ray, no normalisation)
-                const uint2 sc = *(const uint2*)(rng_planes + i);  // jittered screen position (k_wf_rng)
-                primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
+            if (GRID >= 2) {   // ray_cast + alpha walk of the camera ray (mod.rs:182-205) through the camera grid
+                if (GRID == 3) {   // StdRng::seed_from_u64(sample + i * samples), jitter x then y (mod.rs:110-120)
+                    uint32_t w[16];
+                    pt_chacha12_block((uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples, 0u, w);
+                    float sx, sy;
+                    primary_screen(S, it.x, it.y, W.P.width, W.P.height, wf_rng_float(w[0]), wf_rng_float(w[1]), sx, sy);
+                    primary_from_screen(S, sx, sy, o, d);
+                    r1_0 = wf_rng_float(w[2]);
+                    r2_0 = wf_rng_float(w[3]);
+                    later_words = make_uint4(w[4], w[5], w[6], w[7]);
+                } else {
+                    const uint2 sc = *(const uint2*)(rng_planes + i);  // jittered screen position (k_wf_rng)
+                    primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
+                }
+                const uint32_t cell = og_cell(S.cam_grid, d);
+                const float dlen = mag3(d);
+                const float kmax = (dlen > 1.0f ? dlen : 1.0f) * 1.00002f;
+                draw = 2u;   // the pixel jitter
+                if (COUNT) lc.segments++;
+                hit = og_next_hit<COUNT>(S, S.cam_grid, cell, o, d, kmax, INFINITY, -INFINITY, 0u, h, lc);
+                if (ALPHA) {
+                    RawHit kept = h;
+                    bool have_kept = false;
+                    while (hit) {
+                        const float opacity = hit_opacity(S, o, d, h);
+                        if (COUNT) lc.shaded++;
+                        bool stop = opacity >= 1.f;
+                        if (!stop && opacity > 0.001f) stop = wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++) < opacity;
+                        if (stop) break;
+                        kept = h;   // skipped: remember it, look for the next entry of the list
+                        have_kept = true;
+                        if (COUNT) lc.restarts++;
+                        hit = og_next_hit<COUNT>(S, S.cam_grid, cell, o, d, kmax, INFINITY, kept.key, kept.ord, h, lc);
+                    }
+                    if (!hit && have_kept) {   // every hit skipped: the last one is shaded
+                        h = kept;
+                        hit = true;
+                    }
+                }
+            } else {
+                draw = ALPHA ? draws[i] : 2u;   // 2 = the pixel jitter (+ the draws of the alpha walk)
+                hit = unpack_hit(hits[i], h);
+                if (hit) {  // (a missed cast only adds the background: no ray, no normalisation)
+                    const uint2 sc = *(const uint2*)(rng_planes + i);  // jittered screen position (k_wf_rng)
+                    primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
+                }
             }
             if (COUNT) n_new++;
         }
@@ -766,7 +826,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
         hit = unpack_hit(hits[i], h);
         if (out_slot == 0xffffffffu) live = false;  // (records of items outside the image; none since bounce 0 is fused)
     }
-    const uint32_t bounce = W.bounce, bounces = W.P.bounces;
+    const uint32_t bounce = PRIMARY ? 0u : W.bounce, bounces = W.P.bounces;   // (PRIMARY: no Russian roulette code at all)
     bool to_shadow = false, survive = false;
     f3 term0 = mk3(0.f, 0.f, 0.f);
     Surface surf;
@@ -789,21 +849,46 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
         view = -1.f * d;
         ct_init(brdf, ms);
         color = color + mul_ew(thr, ms.emissive);
-        // (thr ⊙ eval_direct) per light; the visibility factor is applied by k_wf_shadow.  The first
-        // light's term stays in registers, the others are recomputed when the record is written.
+        // (thr ⊙ eval_direct) per light.  GRID: the light's visibility is looked up here and the light added at
+        // once, in light order (mod.rs:248-262).  Otherwise (and for a normal too long for the grids' margin) the
+        // visibility factor is applied by the shadow kernel: the first light's term stays in registers, the others
+        // are recomputed when the record is written.
+        const bool inline_lights = GRID != 0 && dot3(surf.normal, surf.normal) <= S.light_grid_max_normal2;
         for (uint32_t li = 0; li < S.n_lights; ++li) {
             const DevLight& L = S.lights[li];
             f3 ldir = L.kind == PT_LIGHT_POINT ? normalize3(surf.pos - ld3(L.vec)) : ld3(L.vec);
             f3 c = mul_ew(thr, ct_eval_direct(brdf, normal, view, -1.f * ldir));
             if (li == 0) term0 = c;
-            if (!wf_light_is_moot(L, c, surf.pos)) to_shadow = true;
+            const bool moot = wf_light_is_moot(L, c, surf.pos);
+            if (GRID != 0 && inline_lights) {
+                if (moot) {
+                    if (COUNT) n_moot++;
+                } else {
+                    const f3 rad = og_light_radiance<ALPHA, COUNT>(S, li, surf.pos, surf.normal, surf.uv, surf.sphere, lc);
+                    if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) color = color + mul_ew(c, rad);
+                }
+            } else if (!moot) {
+                to_shadow = true;
+            }
         }
-        if (COUNT && !to_shadow) n_moot += S.n_lights;
+        if (COUNT && !inline_lights && !to_shadow) n_moot += S.n_lights;
         bool ended = false;
         if (bounce < bounces) {
             next_o = surf.pos + surf.normal * 0.00001f;
-            float r1 = wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++);
-            float r2 = wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++);
+            float r1, r2;
+            if (GRID == 3) {
+                r1 = r1_0;
+                r2 = r2_0;
+                draw += 2u;
+            } else if (PRIMARY && !ALPHA) {   // draws 2 and 3 of the item: staged next to the screen position (k_wf_rng)
+                const uint2 w23 = *(const uint2*)((const uint32_t*)(rng_planes + item) + 2);
+                r1 = wf_rng_float(w23.x);
+                r2 = wf_rng_float(w23.y);
+                draw += 2u;
+            } else {
+                r1 = wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++);
+                r2 = wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++);
+            }
             next_d = ct_sample(brdf, normal, view, r1, r2);
             f3 wgt = ct_eval_indirect(brdf, normal, view, next_d) / 1.0f;
             next_thr = mul_ew(thr, wgt);
@@ -838,6 +923,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
         sh_idx += sh_cnt[1][k];
     }
     __syncthreads();  // sh_cnt / sh_base are rewritten by the next step
+    if (GRID == 3 && survive) rng_planes_out[(size_t)W.cap + item] = later_words;   // draws 4-7 of the path
     if (survive) {
         float4* q = queue_out + (size_t)next_idx * 4;
         q[0] = make_float4(next_o.x, next_o.y, next_o.z, next_d.x);
@@ -867,14 +953,23 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES) void k_wf_shade(D
     }
     // draws made HERE (the alpha walk counts its own): since the value this kernel started from, plus the jitter
     if (COUNT && live)
-        n_draws += draw - (ALPHA ? draws[i] : PRIMARY ? 0u : (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu)) +
-                   ((ALPHA && PRIMARY) ? 2u : 0u);
+        n_draws += GRID >= 2 ? draw
+                             : draw - (ALPHA ? draws[i] : PRIMARY ? 0u : (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu)) +
+                                   ((ALPHA && PRIMARY) ? 2u : 0u);
     }  // grid-stride loop
     if (COUNT && n_draws) atomicAdd(&gctr->rng_draws, (unsigned long long)n_draws);
     if (COUNT && n_new) atomicAdd(&gctr->samples, (unsigned long long)n_new);
     if (COUNT && n_moot) {
         atomicAdd(&gctr->shadow_rays, (unsigned long long)n_moot);
         atomicAdd(&gctr->shadow_skipped, (unsigned long long)n_moot);
+    }
+    if (COUNT && GRID != 0) {
+        atomicAdd(&gctr->segments, (unsigned long long)lc.segments);
+        atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);
+        atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
+        if (GRID >= 2) atomicAdd(&gctr->trace_tris, (unsigned long long)lc.tris);   // (camera casts and shadow casts: not split)
+        if (ALPHA) atomicAdd(&gctr->shaded_hits, (unsigned long long)lc.shaded);
     }
 }
 
