@@ -6,11 +6,14 @@ stand-in scene (500 k triangles, seed 0; the real PS5 ISF is not in the referenc
 128 spp, 5 bounces, Cook–Torrance, FILMIC.  A "step" is one complete render of that frame:
 every rank renders its interleaved 32x32 tiles (global pixel index in the seed formula, so
 the image is bit-identical for any N), then — for N > 1 — one RCCL all-gather of the packed
-u8 framebuffer slices and a scatter into the row-major image on every rank.  The scene, KD-tree
-and textures are resident in HBM before the timed region starts.
+u8 framebuffer slices and a scatter into the row-major image on every rank.  The scene, KD-tree,
+origin grids and textures are resident in HBM before the timed region starts.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (one process per GPU,
+torch.distributed.run, RCCL) before this process makes any GPU call, and exits with their status.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant
 kernel, HIP-event timed inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle —
@@ -22,6 +25,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -43,6 +48,23 @@ def bytes_per_sample(c, spp):
     return floor, ceiling, dict(R_seg=r_seg, R_sh=r_sh, V=v, T=t, H=h)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks (one per GPU) as children, before this
+    process touches the GPU (it never does), and hand their exit status on."""
+    import torch  # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < args.gpus and "PT_BENCH_DEVICE" not in os.environ:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,13 +76,19 @@ def main():
     ap.add_argument("--spp", type=int, default=128)
     ap.add_argument("--bounces", type=int, default=5)
     ap.add_argument("--tonemap", default="FILMIC")
-    ap.add_argument("--scene-flags", type=int, default=0, help="1 = translucent shells (config 5)")
+    ap.add_argument("--scene-flags", type=int, default=0,
+                    help="generator flags: 1 = translucent shells (config 5), 2 = textures, 4 = closed room")
+    ap.add_argument("--opt-flags", type=int, default=0, help="extra pt_opts.flags (4 = PT_FLAG_NO_GRIDS: KD-tree only)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-counters", action="store_true")
     ap.add_argument("--save-png", default=None)
     ap.add_argument("--backend", default="nccl", help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the N > 1 path with several ranks on ONE GPU: set PT_BENCH_DEVICE=0)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import numpy as np
     import torch
@@ -68,8 +96,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if "PT_BENCH_DEVICE" in os.environ:  # rehearsal only: several ranks on one GPU (gloo backend)
@@ -84,6 +112,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: {dist.get_world_size()} ranks came up, --gpus {args.gpus} asked for")
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective buffers live
 
     pta = entry.load_package()
@@ -98,8 +128,8 @@ def main():
 
     prof = pta.Profile.make(args.width, args.height, args.spp, args.bounces, args.tonemap)
     tile = 32
-    opts = pta.Opts.make(flags=pta.PT_FLAG_TIMING, device=local_rank, shard_rank=rank, shard_count=world,
-                         tile_w=tile, tile_h=tile)
+    opts = pta.Opts.make(flags=pta.PT_FLAG_TIMING | args.opt_flags, device=local_rank, shard_rank=rank,
+                         shard_count=world, tile_w=tile, tile_h=tile)
     n_local = int(lib.pt_local_pixel_count(C.byref(prof), C.byref(opts)))
     npix = args.width * args.height
     slice_pixels = n_local
@@ -114,8 +144,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     stage_ms = {k: 0.0 for k in ("generate_ms", "trace_ms", "shade_ms", "shadow_ms", "accumulate_ms", "postprocess_ms",
-                                 "integrate_ms", "total_ms")}
-    launches = {"launches": 0, "stage_launches": 0}
+                                 "integrate_ms", "total_ms", "bounce0_ms")}
+    launches = {"launches": 0, "stage_launches": 0, "bounce0_launches": 0}
 
     def step():
         gscene.render_device(prof, opts, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
@@ -159,51 +189,83 @@ def main():
     total_samples = npix * args.spp * args.steps
     value = total_samples / elapsed / 1e6
 
-    # ---- roofline of the dominant kernel (k_wf_trace: closest-hit ray casts), this rank's shard.
-    # Algorithmic bytes per closest-hit cast (SURVEY §8-d terms that belong to this kernel): the 64 B ray
-    # record read + 16 B hit record written, 8 B per KD node visited, 36 B per primitive tested.
+    # ---- roofline of the dominant kernel, this rank's shard.  Algorithmic bytes are SURVEY §8-d's per-unit terms for
+    # the work the kernel does: 160 B per path segment (64 B ray + 16 B hit record, written and read), 104 B per shadow
+    # ray, 8 B per KD node visited, 36 B per primitive tested, 160 B per shaded hit (96 B vertex attributes + 64 B
+    # material record) - whatever the implementation keeps in registers or caches instead of moving it.
     roofline = None
     counters = None
     if not args.no_counters:
-        copts = pta.Opts.make(flags=pta.PT_FLAG_COUNTERS, device=local_rank, shard_rank=rank, shard_count=world,
-                              tile_w=tile, tile_h=tile)
+        copts = pta.Opts.make(flags=pta.PT_FLAG_COUNTERS | args.opt_flags, device=local_rank, shard_rank=rank,
+                              shard_count=world, tile_w=tile, tile_h=tile)
         gscene.render_device(prof, copts, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
         torch.cuda.synchronize()
         counters = gscene.counters().as_dict()
         floor_b, ceil_b, per = bytes_per_sample(counters, args.spp)
-        n_launch = max(1, launches["launches"])
-        avg_ms = stage_ms["integrate_ms"] / n_launch            # HIP events around every k_wf_trace launch
-        trace_bytes = counters["segments"] * 80 + counters["trace_nodes"] * 8 + counters["trace_tris"] * 36
-        bytes_per_launch = trace_bytes / max(1, n_launch // args.steps)
+        n_items = n_local * args.spp
+        trace_launches = max(1, launches["launches"])
+        kernels = {}
+        if launches["bounce0_launches"]:
+            # the fused bounce-0 kernel (k_wf_shade<GRID >= 2>): ChaCha block, camera cast, shading, shadow casts
+            per_frame = launches["bounce0_launches"] // args.steps
+            b0_bytes = (n_items * 160 + counters["bounce0_shadow_rays"] * 104 + counters["bounce0_tris"] * 36
+                        + counters["bounce0_hits"] * 160 + n_items * 12)
+            kernels["k_wf_shade<GRID> (bounce 0: ChaCha12 block + camera cast + shading + shadow casts)"] = dict(
+                ms_per_frame=stage_ms["bounce0_ms"] / args.steps, launches_per_frame=per_frame,
+                bytes_per_frame=b0_bytes, units_per_launch=n_items // max(1, per_frame), unit="path samples")
+        trace_segments = counters["segments"] - (n_items if launches["bounce0_launches"] else 0)
+        trace_bytes = trace_segments * 80 + counters["trace_nodes"] * 8 + \
+            (counters["trace_tris"] - (counters["bounce0_tris"] if launches["bounce0_launches"] else 0)) * 36
+        trace_bytes = max(trace_bytes, trace_segments * 80)
+        kernels["k_wf_trace (closest-hit KD-tree casts)"] = dict(
+            ms_per_frame=stage_ms["integrate_ms"] / args.steps, launches_per_frame=trace_launches // args.steps,
+            bytes_per_frame=trace_bytes, units_per_launch=trace_segments // max(1, trace_launches // args.steps),
+            unit="ray casts")
+        name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms_per_frame"])
+        avg_ms = dom["ms_per_frame"] / max(1, dom["launches_per_frame"])
+        bytes_per_launch = dom["bytes_per_frame"] / max(1, dom["launches_per_frame"])
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        # wall time of the kernel pipeline (the shadow casts overlap the next trace, so the stages do not add up)
+        # wall time of the kernel pipeline (shadow casts may overlap the next trace, so the stages do not add up)
         kernel_total = stage_ms["total_ms"] / args.steps
-        pipeline = ceil_b * n_local * args.spp / (kernel_total * 1e-3) / 1e9
-        traffic = l1_rate = None
+        pipeline = ceil_b * n_items / (kernel_total * 1e-3) / 1e9
+        # HBM traffic from the PMC passes (separate rocprofv3 --pmc runs, tools/pmc_profile.sh): not measured in this
+        # run - read from the committed summary of the same workload and code, and labelled as such
+        traffic = valu_rate = traffic_src = None
         tf = ROOT / "profiles" / "latest_traffic.json"
         if tf.exists():
             try:
                 rec = json.loads(tf.read_text())
-                if rec.get("workload") == [args.tris, args.width, args.height, args.spp, args.bounces, world]:
+                if rec.get("workload") == [args.tris, args.width, args.height, args.spp, args.bounces, world] and \
+                        rec.get("kernel", "").split("<")[0] == name.split("<")[0].split(" ")[0] and not args.opt_flags:
                     traffic = rec.get("hbm_bytes_per_launch")
-                    l1_rate = rec.get("tcp_accesses_per_cu_cycle")
+                    valu_rate = rec.get("valu_insts_per_cu_cycle")
+                    traffic_src = f"profiles/latest_traffic.json <- {rec.get('source')}"
             except Exception:
                 traffic = None
         copy_gbs = pta.measure_copy_bandwidth(local_rank, 2 << 30, 5)   # achievable HBM rate on this box
-        roofline = {"bound": "hbm", "kernel": "k_wf_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
+                    "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+                    # what the kernel actually runs against (PMC): vector-instruction issue, 1.0 per CU-cycle = the ceiling
+                    "valu_insts_per_cu_cycle": valu_rate,
                     "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
-                    # from the same PMC pass as `traffic`: vector-L1 accesses per CU-cycle of this kernel (~1.1 = the
-                    # rate scattered lane accesses get through the L1: what the kernel is actually limited by)
-                    "l1_accesses_per_cu_cycle": l1_rate,
-                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_launch // args.steps,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": dom["launches_per_frame"],
+                    "units_per_launch": dom["units_per_launch"], "unit_name": dom["unit"],
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                    "algorithmic_bytes_per_unit": round(bytes_per_launch / max(1, dom["units_per_launch"]), 1),
+                    "kernels": {k: {"ms_per_step": round(v["ms_per_frame"], 3), "launches_per_step": v["launches_per_frame"],
+                                    "algorithmic_GBps": round(v["bytes_per_frame"] / max(1e-9, v["ms_per_frame"] * 1e-3) / 1e9, 1)}
+                                for k, v in kernels.items()},
                     "pipeline": {"algorithmic_bytes_per_sample": round(ceil_b, 1),
                                  "queue_floor_bytes_per_sample": round(floor_b, 1),
                                  "kernel_ms_per_step": round(kernel_total, 3),
                                  "achieved_GBps": round(pipeline, 1), "frac": round(pipeline / HBM_PEAK_GBS, 5),
-                                 "queue_floor_frac": round(floor_b * n_local * args.spp / (kernel_total * 1e-3) / 1e9
-                                                           / HBM_PEAK_GBS, 5)},
+                                 "queue_floor_frac": round(floor_b * n_items / (kernel_total * 1e-3) / 1e9
+                                                           / HBM_PEAK_GBS, 5),
+                                 "Grays_per_s": round((counters["segments"] + counters["shadow_rays"]
+                                                       - counters["shadow_skipped"]) / (kernel_total * 1e-3) / 1e9, 3)},
                     "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
                     "per_sample": {k: round(v, 3) for k, v in per.items()}}
 
@@ -254,7 +316,9 @@ def main():
                                    f"{args.bounces} bounces, COOK_TORRANCE, {args.tonemap}",
                        "parallelism": f"{world} x tile-sharded (32x32 interleaved)" + (", RCCL all-gather of u8 framebuffer" if world > 1 else ""),
                        "kd": {k: info[k] for k in ("n_prims", "n_kd_nodes", "n_kd_leaves", "n_leaf_refs", "kd_depth")},
-                       "setup_seconds": round(setup_s, 2), "kd_build_seconds": round(info["kd_build_seconds"], 2)},
+                       "origin_grids": {k: info[k] for k in ("cam_grid_res", "light_grids", "grid_refs")},
+                       "setup_seconds": round(setup_s, 2), "kd_build_seconds": round(info["kd_build_seconds"], 2),
+                       "grid_build_seconds": round(info["grid_build_seconds"], 2)},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -243,6 +243,9 @@ typedef struct pt_timing {
     float shadow_ms;
     float accumulate_ms;
     uint32_t stage_launches;  /* all integrator launches                           */
+    uint32_t bounce0_launches; /* launches of the fused bounce-0 kernel (k_wf_shade<GRID >= 2>: ChaCha block,
+                                  camera cast, shading, shadow casts); 0 when the scene has no such kernel */
+    float bounce0_ms;         /* sum of their HIP-event durations                  */
 } pt_timing;
 
 /* Exact work counters from the instrumented variant (PT_FLAG_COUNTERS);
@@ -262,6 +265,10 @@ typedef struct pt_counters {
     uint64_t trace_tris;           /* closest-hit casts (the rest: shadow casts)      */
     uint64_t shadow_skipped;       /* of shadow_rays: not cast, because the light's BRDF term is exactly 0
                                     * and the visibility cannot change the colour                     */
+    uint64_t bounce0_hits;         /* camera rays that hit a surface (shaded at bounce 0)             */
+    uint64_t bounce0_shadow_rays;  /* shadow rays cast by the fused bounce-0 kernel (k_wf_shade<GRID >= 2>)  */
+    uint64_t bounce0_tris;         /* primitive tests of that kernel (camera casts + shadow casts)    */
+    uint64_t grid_tris;            /* of tris_tested: made through origin grids (camera / point lights) */
 } pt_counters;
 
 int pt_get_timing(const pt_scene* scene, pt_timing* out);

@@ -34,7 +34,10 @@ const pt_scene_desc* pth_scene_desc(const pth_scene* s);
  *   target_tris  approximate triangle count (500000 for BASELINE cfg 3/4)
  *   seed         PCG32 seed for the vertex jitter (0 for the BASELINE configs)
  *   flags        bit0: shells get opacity.factor 0.5 + a 1024^2 checker
- *                opacity texture (BASELINE cfg 5) */
+ *                opacity texture (BASELINE cfg 5)
+ *                bit1: procedural textures of every other kind: the shells get a
+ *                normal map, metalness and roughness textures (one of them an
+ *                albedo texture too), the core an emissive texture */
 int pth_scene_generate_ps5(uint64_t target_tris, uint64_t seed, uint32_t flags, pth_scene** out);
 
 /* Write a scene as ISF JSON (+ textures as PNG next to it). */

@@ -27,6 +27,9 @@ def lib():
         L.pto_scene_destroy.argtypes = [vp]
         L.pto_scene_destroy.restype = None
         L.pto_render.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp, vp]
+        L.pto_render_partial.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, vp, vp, vp]
+        L.pto_rng_key.argtypes = [C.c_uint64, vp]
+        L.pto_chacha_block.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
         L.pto_post_process.argtypes = [vp, vp, C.c_uint64, vp]
         L.pto_debug_render.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_int)]
         L.pto_trace_rays_all.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
@@ -62,16 +65,17 @@ class OracleScene:
         self._keep = keepalive
         _check(lib().pto_scene_create(C.cast(desc_ptr, C.c_void_p), mode, C.byref(self.handle)))
 
-    def render(self, profile, pixel_begin=0, pixel_end=0, threads=0):
-        """Returns (rgb8 [n,3], accum [n,3] f32 = SUM over samples, stats dict)."""
+    def render(self, profile, pixel_begin=0, pixel_end=0, threads=0, sample_count=0):
+        """Returns (rgb8 [n,3], accum [n,3] f32 = SUM over samples, stats dict).  sample_count: only the first
+        that many sample passes (the viewer feed after sample_count passes)."""
         npix = profile.width * profile.height
         end = pixel_end or npix
         n = end - pixel_begin
         rgb = np.empty((n, 3), np.uint8)
         acc = np.empty((n, 3), np.float32)
         stats = (C.c_uint64 * len(STAT_NAMES))()
-        _check(lib().pto_render(self.handle, C.byref(profile), pixel_begin, end, threads, rgb.ctypes.data,
-                                acc.ctypes.data, C.byref(stats)))
+        _check(lib().pto_render_partial(self.handle, C.byref(profile), sample_count or profile.samples, pixel_begin, end,
+                                        threads, rgb.ctypes.data, acc.ctypes.data, C.byref(stats)))
         return rgb, acc, dict(zip(STAT_NAMES, (int(v) for v in stats)))
 
     def debug_render(self, width, height):
@@ -125,6 +129,19 @@ def rng_words(seeds, n_words):
     seeds = np.ascontiguousarray(seeds, np.uint64)
     out = np.zeros((len(seeds), n_words), np.uint32)
     _check(lib().pto_rng_words(seeds.ctypes.data, len(seeds), n_words, out.ctypes.data))
+    return out
+
+
+def rng_key(seed):
+    out = np.zeros(8, np.uint32)
+    _check(lib().pto_rng_key(int(seed), out.ctypes.data))
+    return out
+
+
+def chacha_block(key8, counter=0, rounds=12):
+    key8 = np.ascontiguousarray(key8, np.uint32)
+    out = np.zeros(16, np.uint32)
+    _check(lib().pto_chacha_block(key8.ctypes.data, int(counter), rounds, out.ctypes.data))
     return out
 
 

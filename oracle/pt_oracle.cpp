@@ -114,7 +114,8 @@ struct StdRng {
         draws = 0;
     }
     static inline uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
-    void refill() {
+    // ChaCha block function: constants "expand 32-byte k", 8 key words, 64-bit block counter, two zero words
+    static void block(const uint32_t key[8], uint64_t counter, int double_rounds, uint32_t out[16]) {
         uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
                           key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
                           (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
@@ -125,12 +126,15 @@ struct StdRng {
     x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 12);                  \
     x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 8);                   \
     x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 7);
-        for (int r = 0; r < 6; ++r) {  // 12 rounds = 6 double rounds
+        for (int r = 0; r < double_rounds; ++r) {
             QR(0, 4, 8, 12) QR(1, 5, 9, 13) QR(2, 6, 10, 14) QR(3, 7, 11, 15)
             QR(0, 5, 10, 15) QR(1, 6, 11, 12) QR(2, 7, 8, 13) QR(3, 4, 9, 14)
         }
 #undef QR
-        for (int i = 0; i < 16; ++i) buf[i] = x[i] + s[i];
+        for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
+    }
+    void refill() {
+        block(key, counter, 6, buf);  // StdRng = ChaCha12: 12 rounds = 6 double rounds
         ++counter;
         index = 0;
     }
@@ -900,8 +904,16 @@ void pto_scene_destroy(pto_scene* s) { delete s; }
 
 int pto_render(const pto_scene* s, const pt_profile* profile, uint64_t pixel_begin, uint64_t pixel_end,
                int threads, uint8_t* rgb8, float* accum, pto_stats* stats) {
+    return pto_render_partial(s, profile, profile ? profile->samples : 0, pixel_begin, pixel_end, threads, rgb8, accum, stats);
+}
+
+// The first `sample_count` sample passes of a render of `profile` (seeds use profile.samples, mod.rs:110-112);
+// rgb8 = post_processing(sum / sample_count): what the viewer feed shows after that many passes (mod.rs:133-141).
+int pto_render_partial(const pto_scene* s, const pt_profile* profile, uint32_t sample_count, uint64_t pixel_begin,
+                       uint64_t pixel_end, int threads, uint8_t* rgb8, float* accum, pto_stats* stats) {
     if (!s || !profile) return set_err(PT_ERR_INVALID, "pto_render: null argument");
     const pt_profile p = *profile;
+    if (sample_count == 0 || sample_count > p.samples) return set_err(PT_ERR_INVALID, "pto_render: bad sample count");
     uint64_t npix = (uint64_t)p.width * p.height;
     if (pixel_end == 0) pixel_end = npix;
     if (pixel_begin > pixel_end || pixel_end > npix) return set_err(PT_ERR_INVALID, "pto_render: bad pixel range");
@@ -915,7 +927,7 @@ int pto_render(const pto_scene* s, const pt_profile* profile, uint64_t pixel_beg
         for (int64_t ii = (int64_t)pixel_begin; ii < (int64_t)pixel_end; ++ii) {
             uint64_t i = (uint64_t)ii;
             V3 pixel = v3(0, 0, 0);  // the reference's `buffer[i]` (mod.rs:81)
-            for (uint32_t current_sample = 1; current_sample < p.samples + 1; ++current_sample) {
+            for (uint32_t current_sample = 1; current_sample < sample_count + 1; ++current_sample) {
                 StdRng rng((uint64_t)current_sample + i * (uint64_t)p.samples);  // mod.rs:110-112
                 Ray ray = primary_ray(*s, p, i, rng);
                 V3 color = render_pixel(c, ray, rng);
@@ -930,7 +942,7 @@ int pto_render(const pto_scene* s, const pt_profile* profile, uint64_t pixel_beg
                 accum[3 * o + 1] = pixel.y;
                 accum[3 * o + 2] = pixel.z;
             }
-            if (rgb8) post_processing(p.tonemap, pixel / (float)p.samples, rgb8 + 3 * o);  // mod.rs:150-162
+            if (rgb8) post_processing(p.tonemap, pixel / (float)sample_count, rgb8 + 3 * o);  // mod.rs:150-162, 138
         }
 #pragma omp critical
         {
@@ -1052,6 +1064,21 @@ int pto_rng_words(const uint64_t* seeds, uint64_t n_seeds, uint32_t n_words, uin
         StdRng rng(seeds[i]);
         for (uint32_t w = 0; w < n_words; ++w) out[i * n_words + w] = rng.next_u32();
     }
+    return PT_OK;
+}
+
+// Known-answer hooks: the PCG32-expanded key of seed_from_u64, and the bare block function with a
+// chosen round count (20 rounds, zero key: the RFC 7539 keystream ade0b876 903df1a0 e56a5d40 28bd8653 ...).
+int pto_rng_key(uint64_t seed, uint32_t* out8) {
+    if (!out8) return set_err(PT_ERR_INVALID, "pto_rng_key: null argument");
+    StdRng rng(seed);
+    memcpy(out8, rng.key, sizeof rng.key);
+    return PT_OK;
+}
+
+int pto_chacha_block(const uint32_t* key8, uint64_t counter, uint32_t rounds, uint32_t* out16) {
+    if (!key8 || !out16 || rounds == 0 || (rounds & 1u) || rounds > 64) return set_err(PT_ERR_INVALID, "pto_chacha_block: bad argument");
+    StdRng::block(key8, counter, (int)(rounds / 2), out16);
     return PT_OK;
 }
 

@@ -49,6 +49,11 @@ typedef struct pto_stats {
 int pto_render(const pto_scene* s, const pt_profile* profile, uint64_t pixel_begin,
                uint64_t pixel_end, int threads, uint8_t* rgb8, float* accum, pto_stats* stats);
 
+/* The first sample_count sample passes of the same render (seeds keep profile->samples as their stride);
+ * rgb8 = post_processing(sum / sample_count), the viewer feed of renderer/mod.rs:133-141. */
+int pto_render_partial(const pto_scene* s, const pt_profile* profile, uint32_t sample_count, uint64_t pixel_begin,
+                       uint64_t pixel_end, int threads, uint8_t* rgb8, float* accum, pto_stats* stats);
+
 /* debug_render (renderer/debug_renderer.rs): 7 RGB8 planes, see pt_debug_render in ptgpu.h. */
 int pto_debug_render(const pto_scene* s, uint32_t width, uint32_t height, uint8_t* planes, int* any_hit);
 
@@ -65,6 +70,11 @@ int pto_intersect_triangles(const float* rays, const float* tris, uint64_t n, pt
 
 /* StdRng::seed_from_u64(seed) -> first n_words of next_u32(). */
 int pto_rng_words(const uint64_t* seeds, uint64_t n_seeds, uint32_t n_words, uint32_t* out);
+
+/* Known-answer hooks: the 8 key words seed_from_u64 expands `seed` into (PCG32), and the ChaCha block function
+ * with a chosen (even) number of rounds. */
+int pto_rng_key(uint64_t seed, uint32_t* out8);
+int pto_chacha_block(const uint32_t* key8, uint64_t counter, uint32_t rounds, uint32_t* out16);
 
 /* libm as the reference calls it: fn 0 powf(x, 1/2.2f), 1 acosf, 2 sinf, 3 cosf. */
 int pto_eval_math(int fn, const float* x, uint64_t n, float* out);

@@ -96,7 +96,7 @@ class Timing(C.Structure):
     _fields_ = [("launches", C.c_uint32), ("integrate_ms", C.c_float), ("postprocess_ms", C.c_float),
                 ("total_ms", C.c_float), ("generate_ms", C.c_float), ("trace_ms", C.c_float),
                 ("shade_ms", C.c_float), ("shadow_ms", C.c_float), ("accumulate_ms", C.c_float),
-                ("stage_launches", C.c_uint32)]
+                ("stage_launches", C.c_uint32), ("bounce0_launches", C.c_uint32), ("bounce0_ms", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -106,7 +106,8 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "shadow_rays", "nodes_visited",
                                           "tris_tested", "shaded_hits", "rng_draws", "restarts",
                                           "max_nodes_per_cast", "casts_over_1k_nodes", "trace_nodes", "trace_tris",
-                                          "shadow_skipped")]
+                                          "shadow_skipped", "bounce0_hits", "bounce0_shadow_rays", "bounce0_tris",
+                                          "grid_tris")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

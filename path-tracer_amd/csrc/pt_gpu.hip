@@ -902,6 +902,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     uint32_t launches = 0, stage_launches = 0;
     // (stage id, first event index) of every timed launch: 0 generate 1 trace 2 shade 3 shadow 4 accumulate 5 fused
     std::vector<std::pair<int, size_t>> marks;
+    std::vector<size_t> fused_marks;   // first event index of every fused bounce-0 launch (k_wf_shade<GRID >= 2>)
     hipStream_t stage_stream = stream;
     auto stage_begin = [&](int stage) {
         if (!timing) return;
@@ -1057,6 +1058,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     }
                     // shade(b) reads the colours shadow(b-1) patched and refills the shadow queue it consumed
                     if (st_shadow != st_main && b > 0) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
+                    if (timing && grid_mode >= 2) fused_marks.push_back(ev);
                     stage_begin(2);
                     if (grid_mode == 3) {
                         if (counting) PT_LAUNCH_SHADE(false, true, true, 3);
@@ -1164,7 +1166,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             *slot[m.first] += ms;
             if (dump) fprintf(stderr, "[pt] stage %d  %.3f ms\n", m.first, ms);
         }
-        if (mode == 2) t.integrate_ms = t.trace_ms;  // dominant kernel of the wavefront integrator
+        if (mode == 2) t.integrate_ms = t.trace_ms;  // k_wf_trace launches of the wavefront integrator
+        for (size_t m : fused_marks) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, s.events[m], s.events[m + 1]));
+            t.bounce0_ms += ms;
+            ++t.bounce0_launches;
+        }
         HIP_CHECK(hipEventElapsedTime(&t.postprocess_ms, s.events[ev_post], s.events[ev_post + 1]));
         HIP_CHECK(hipEventElapsedTime(&t.total_ms, s.events[0], s.events[ev_post + 1]));
         s.timing = t;
@@ -1174,7 +1182,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         HIP_CHECK(hipMemcpy(&c, s.counter_buf.p, sizeof c, hipMemcpyDeviceToHost));
         s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
                                  c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes,
-                                 c.trace_nodes, c.trace_tris, c.shadow_skipped};
+                                 c.trace_nodes, c.trace_tris, c.shadow_skipped, c.bounce0_hits, c.bounce0_shadow_rays,
+                                 c.bounce0_tris, c.grid_tris};
         if (getenv("PT_DEBUG_STAMPS"))
             fprintf(stderr, "[pt] trace stamps: refill %llu walk %llu leaf %llu complete %llu cycles | walk lanes/step %.1f (%llu steps) | leaf lanes/run %.1f (%llu runs)\n",
                     c.stamps[0], c.stamps[1], c.stamps[2], c.stamps[3], c.stamps[5] ? (double)c.stamps[4] / c.stamps[5] : 0.0,

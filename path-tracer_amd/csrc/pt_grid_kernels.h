@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_og_primary(DevScene S, WfParams W, cons
         atomicAdd(&gctr->segments, (unsigned long long)lc.segments);
         atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
         atomicAdd(&gctr->trace_tris, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->grid_tris, (unsigned long long)lc.tris);
         atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
         if (ALPHA) atomicAdd(&gctr->shaded_hits, (unsigned long long)lc.shaded);
         if (ALPHA) atomicAdd(&gctr->rng_draws, (unsigned long long)lc.shadow_rays);
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256) void k_og_shadow(DevScene S, WfParams W, const
         atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);
         atomicAdd(&gctr->shadow_skipped, (unsigned long long)n_skipped);
         atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->grid_tris, (unsigned long long)lc.tris);
         atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
     }
 }

@@ -737,7 +737,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
     static_assert(GRID < 2 || PRIMARY, "the camera grid serves bounce 0");
     static_assert(GRID != 3 || !ALPHA, "translucent scenes stage their RNG words (the alpha walk draws)");
     const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
-    uint32_t n_draws = 0, n_new = 0, n_moot = 0;
+    uint32_t n_draws = 0, n_new = 0, n_moot = 0, n_hits = 0, n_cam_tris = 0;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};   // (GRID: casts made here)
     __shared__ uint32_t sh_cnt[2][WF_SHADE_THREADS / 64];
     __shared__ uint32_t sh_base[2];
@@ -840,7 +840,9 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
     }
     Brdf brdf;
     f3 normal = mk3(0, 0, 0), view = mk3(0, 0, 0);
+    if (COUNT && GRID >= 2) n_cam_tris = lc.tris;   // (so far: the camera casts; the shadow casts follow)
     if (live && hit) {
+        if (COUNT) n_hits++;
         make_surface(S, o, d, h, surf);
         MatSample ms;
         material_sample(S, surf.model, surf.sphere, surf.uv, ms);
@@ -963,12 +965,18 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
         atomicAdd(&gctr->shadow_rays, (unsigned long long)n_moot);
         atomicAdd(&gctr->shadow_skipped, (unsigned long long)n_moot);
     }
+    if (COUNT && PRIMARY && n_hits) atomicAdd(&gctr->bounce0_hits, (unsigned long long)n_hits);
     if (COUNT && GRID != 0) {
         atomicAdd(&gctr->segments, (unsigned long long)lc.segments);
         atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);
         atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->grid_tris, (unsigned long long)lc.tris);
         atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
-        if (GRID >= 2) atomicAdd(&gctr->trace_tris, (unsigned long long)lc.tris);   // (camera casts and shadow casts: not split)
+        if (GRID >= 2) {
+            atomicAdd(&gctr->trace_tris, (unsigned long long)n_cam_tris);
+            atomicAdd(&gctr->bounce0_tris, (unsigned long long)lc.tris);
+            atomicAdd(&gctr->bounce0_shadow_rays, (unsigned long long)lc.shadow_rays);
+        }
         if (ALPHA) atomicAdd(&gctr->shaded_hits, (unsigned long long)lc.shaded);
     }
 }

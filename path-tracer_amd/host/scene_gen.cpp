@@ -134,7 +134,50 @@ void generate(uint64_t target, uint64_t seed, uint32_t flags, pth_scene& sc) {
     if (target > 200000000ull) fail(PT_ERR_INVALID, "target_tris too large");
     Pcg32 rng(seed);
     const double jitter = 2e-4;
-    const bool alpha = flags & 1u;
+    const bool alpha = flags & 1u, textured = flags & 2u;
+    // procedural textures (flags bit 1): every texture kind of internal/material.rs:132-214 on the shells and the core
+    auto add_texture = [&](uint32_t w, uint32_t h, uint32_t channels, const char* name,
+                           const std::function<void(uint32_t, uint32_t, uint8_t*)>& texel) {
+        pt_texture t{};
+        t.offset = sc.texels.size();
+        t.width = w;
+        t.height = h;
+        t.channels = channels;
+        sc.texels.resize(sc.texels.size() + (size_t)w * h * channels);
+        uint8_t* px = sc.texels.data() + t.offset;
+        for (uint32_t y = 0; y < h; ++y)
+            for (uint32_t x = 0; x < w; ++x) texel(x, y, px + ((size_t)y * w + x) * channels);
+        sc.textures.push_back(t);
+        sc.texture_paths.push_back(name);
+        return (int32_t)sc.textures.size() - 1;
+    };
+    int32_t tex_normal = -1, tex_metal = -1, tex_rough = -1, tex_emissive = -1, tex_albedo = -1;
+    if (textured) {
+        tex_normal = add_texture(256, 256, 3, "generated:bumps_normal_256", [](uint32_t x, uint32_t y, uint8_t* p) {
+            // a field of round bumps: tangent-space normal (dx, dy, 1) normalised, stored as n * 0.5 + 0.5
+            double fx = (x % 32) / 32.0 - 0.5, fy = (y % 32) / 32.0 - 0.5, r2 = fx * fx + fy * fy;
+            double dx = r2 < 0.2 ? -1.6 * fx : 0.0, dy = r2 < 0.2 ? -1.6 * fy : 0.0;
+            double l = std::sqrt(dx * dx + dy * dy + 1.0);
+            p[0] = (uint8_t)std::lround((dx / l * 0.5 + 0.5) * 255.0);
+            p[1] = (uint8_t)std::lround((dy / l * 0.5 + 0.5) * 255.0);
+            p[2] = (uint8_t)std::lround((1.0 / l * 0.5 + 0.5) * 255.0);
+        });
+        tex_metal = add_texture(64, 64, 1, "generated:stripes_metalness_64",
+                                [](uint32_t x, uint32_t, uint8_t* p) { p[0] = (x / 8) % 2 ? 230 : 12; });
+        tex_rough = add_texture(64, 32, 1, "generated:ramp_roughness_64x32",
+                                [](uint32_t x, uint32_t y, uint8_t* p) { p[0] = (uint8_t)(40 + 3 * x + (y % 8 < 4 ? 0 : 20)); });
+        tex_emissive = add_texture(128, 128, 3, "generated:dots_emissive_128", [](uint32_t x, uint32_t y, uint8_t* p) {
+            bool dot = ((x % 16) - 8) * ((x % 16) - 8) + ((y % 16) - 8) * ((y % 16) - 8) < 10;
+            p[0] = dot ? 255 : 0;
+            p[1] = dot ? (uint8_t)(60 + x) : 0;
+            p[2] = dot ? (uint8_t)(20 + y) : 4;
+        });
+        tex_albedo = add_texture(96, 96, 3, "generated:weave_albedo_96", [](uint32_t x, uint32_t y, uint8_t* p) {
+            p[0] = (uint8_t)(150 + 100 * ((x / 12 + y / 12) % 2));
+            p[1] = (uint8_t)(140 + (x * 7 + y * 3) % 100);
+            p[2] = (uint8_t)(130 + (y * 5) % 120);
+        });
+    }
 
     // fixed parts scale gently with the budget
     uint32_t g_ground = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(8, (uint64_t)std::sqrt(target / 128.0)));
@@ -158,7 +201,16 @@ void generate(uint64_t target, uint64_t seed, uint32_t flags, pth_scene& sc) {
     // 2. glossy dark core (closed ellipsoid-like body)
     uint32_t cs, ct;
     dims(core_tris, 1.0, cs, ct);
-    begin_mesh(sc, plain(0.03f, 0.03f, 0.035f, 0.25f, 0.f), first);
+    {
+        pt_material core = plain(0.03f, 0.03f, 0.035f, 0.25f, 0.f);
+        if (textured) {   // glowing dots on the dark core: emissive texture x factor (material.rs:189-201)
+            core.tex_emissive = tex_emissive;
+            core.emissive[0] = 0.8f;
+            core.emissive[1] = 0.6f;
+            core.emissive[2] = 1.5f;
+        }
+        begin_mesh(sc, core, first);
+    }
     add_patch(sc,
               [](double s, double t) {
                   double th = M_PI * (0.02 + 0.96 * t), ph = 2 * M_PI * s;
@@ -190,6 +242,14 @@ void generate(uint64_t target, uint64_t seed, uint32_t flags, pth_scene& sc) {
         if (alpha) {
             m.opacity = 0.5f;
             m.tex_opacity = opacity_tex;
+        }
+        if (textured) {   // normal map (hit.rs:64-71), metalness / roughness / albedo textures (material.rs:132-172)
+            m.tex_normal = tex_normal;
+            m.tex_metalness = tex_metal;
+            m.metalness = 0.9f;
+            m.tex_roughness = tex_rough;
+            m.roughness = 0.8f;
+            if (side > 0) m.tex_albedo = tex_albedo;
         }
         begin_mesh(sc, m, first);
         double sd = side;

@@ -1,6 +1,7 @@
 """N > 1 path on CPU: world_size-2 (and 3) gloo ranks shard the frame with the product's tile map
-(pt_local_pixel_map — host code, no GPU), render their packed slices with the oracle, all-gather the padded
-u8 slices exactly as bench.py does, and rebuild the row-major image.  It must equal the unsharded render."""
+(pt_local_pixel_map — host code, no GPU), each rank RENDERS ITS OWN SHARD with the oracle (tile row by tile row,
+global pixel index in the seed), all-gathers the padded u8 slices exactly as bench.py does, and rebuilds the
+row-major image.  It must equal the unsharded render."""
 import os
 import subprocess
 import sys
@@ -24,14 +25,18 @@ WORKER = textwrap.dedent('''
     opts = pta.Opts.make(shard_rank=rank, shard_count=world, tile_w=tile, tile_h=tile)
     idx = pta.local_pixel_map(prof, opts)
     osc = oracle.OracleScene(scene.desc, oracle.PTO_BVH)
-    full_rgb, full_acc, _ = osc.render(prof)           # every rank: the unsharded truth
-    # this rank's pixels, rendered independently in packed order (pixel ranges of length 1 would be slow:
-    # render the covering range and pick, the seed formula only depends on the global index)
-    local_rgb = full_rgb[idx].copy()
-    probe = [int(idx[0]), int(idx[len(idx) // 2]), int(idx[-1])]
-    for p in probe:                                     # spot-check genuinely independent renders
-        rgb1, acc1, _ = osc.render(prof, p, p + 1, 1)
-        assert np.array_equal(rgb1[0], full_rgb[p]) and np.array_equal(acc1[0].view(np.uint32), full_acc[p].view(np.uint32))
+    # this rank's pixels, rendered by this rank only: the packed order is tile after tile, row by row inside a tile,
+    # so every run of consecutive global indices (one tile row) is one oracle call over [begin, end)
+    local_rgb = np.zeros((len(idx), 3), np.uint8)
+    breaks = np.nonzero(np.diff(idx.astype(np.int64)) != 1)[0] + 1
+    n_runs = 0
+    for run in np.split(np.arange(len(idx)), breaks):
+        begin, end = int(idx[run[0]]), int(idx[run[-1]]) + 1
+        rgb_run, _, _ = osc.render(prof, begin, end, 1)
+        local_rgb[run] = rgb_run
+        n_runs += 1
+    assert n_runs >= len(idx) // tile                   # (really tile rows, not one big range)
+    full_rgb, _, _ = osc.render(prof)                   # the unsharded truth, to compare the assembled frame with
     n_local = torch.tensor([len(idx)])
     dist.all_reduce(n_local, op=dist.ReduceOp.MAX)
     slice_pixels = int(n_local.item())

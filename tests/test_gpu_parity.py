@@ -341,6 +341,35 @@ def test_long_normals_leave_the_light_grid(pta, oracle, tmp_path):
     assert exact == 1.0 and same
 
 
+@pytest.mark.parametrize("flags", [2, 3])
+def test_textured_generated_scene_is_bit_identical(pta, oracle, flags):
+    """Normal maps (hit.rs:55-82: TBN frame from the uv derivatives, hit.rs:116-127) and the emissive / metalness /
+    roughness / albedo texture fetches (material.rs:132-214) - no reference test pins them, so GPU vs oracle is the
+    check: the generated scene with flag bit 1 carries every texture kind (flags 3: plus translucent shells)."""
+    scene = pta.HostScene.generate_ps5(16000, seed=0, flags=flags)
+    mats = scene.desc.contents.materials
+    assert any(mats[i].tex_normal >= 0 for i in range(scene.desc.contents.n_materials))
+    g = pta.GpuScene(scene)
+    prof = pta.Profile.make(240, 135, 8, 6, "REINHARD")
+    ok, u8_ok, exact, same_image = compare_render(pta, oracle, scene, g, prof)
+    assert exact == 1.0 and same_image
+    # the same through the KD-only wavefront path and the megakernel
+    rgb, acc = g.render(prof)
+    for f in (pta.PT_FLAG_NO_GRIDS, pta.PT_FLAG_MEGAKERNEL):
+        rgb2, acc2 = g.render(prof, pta.Opts.make(flags=f))
+        assert np.array_equal(bits(acc), bits(acc2)) and np.array_equal(rgb, rgb2), f
+    # G-buffer planes see the textures
+    got = g.debug_render(240, 135)
+    ref = oracle.OracleScene(scene.desc, oracle.PTO_BVH).debug_render(240, 135)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+    assert len(np.unique(got["normal"].reshape(-1, 3), axis=0)) > 200      # the bump field, not a smooth shell
+    assert len(np.unique(got["roughness"].reshape(-1, 3), axis=0)) > 20 and got["emissive"].any()
+    # ... and the textures matter: the untextured scene renders differently
+    plain = pta.GpuScene(pta.HostScene.generate_ps5(16000, seed=0, flags=flags & 1))
+    assert not np.array_equal(plain.render(prof)[0], rgb)
+
+
 def _write_isf(tmp_path, name, models, lights, background=(0.25, 0.5, 1.0)):
     import json
     cam = {"transform": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 4, 1]], "fov": 0.8, "zfar": 100.0, "znear": 0.1}
@@ -392,9 +421,10 @@ def test_debug_textures_without_hits_write_nothing(pta, oracle, tmp_path):
     assert oracle.OracleScene(scene.desc, oracle.PTO_BVH).debug_render(32, 16) == {}
 
 
-def test_progressive_preview_matches_partial_renders(pta, gpu_scene_cache):
-    """Viewer feed (renderer/mod.rs:133-141): after k of N samples the preview is post_processing(sum_k / k); the
-    last preview is the final image and the preview hook does not disturb the render."""
+def test_progressive_preview_matches_partial_renders(pta, oracle, scene_cache, gpu_scene_cache):
+    """Viewer feed (renderer/mod.rs:133-141): after k of N samples the preview is post_processing(sum_k / k) - compared
+    with the oracle's first k sample passes of the same N-sample render; the last preview is the final image and the
+    preview hook does not disturb the render."""
     g = gpu_scene_cache("reflection")
     prof = pta.Profile.make(96, 64, 12, 3)
     seen = []
@@ -404,6 +434,10 @@ def test_progressive_preview_matches_partial_renders(pta, gpu_scene_cache):
 
     rgb, acc = g.render(prof, pta.Opts.make(sample_batch=5, preview=preview))
     assert [d for d, _, _ in seen] == [5, 10, 12] and all(t == 12 for _, t, _ in seen)
+    osc = oracle.OracleScene(scene_cache("reflection").desc, oracle.PTO_BVH)
+    for done, _, preview_rgb in seen:                # every preview = the oracle after `done` sample passes
+        o_rgb, _, _ = osc.render(prof, sample_count=done)
+        assert np.array_equal(preview_rgb, o_rgb), done
     assert np.array_equal(seen[-1][2], rgb)          # the last preview is the final image
     assert not np.array_equal(seen[0][2], rgb)       # earlier ones are noisier
     rgb_plain, acc_plain = g.render(prof)
@@ -478,41 +512,52 @@ def test_config3_full_size(pta, oracle, ps5_scene):
     assert seen.all()
 
 
-def test_config4_bounces_and_samples(pta, oracle, ps5_scene):
-    """BASELINE config 4's path length (8 bounces) on the same scene; 512 spp is the sum of four 128-sample
-    renders only through the seed formula, so the sample count is exercised with a prime (131) instead."""
+def test_config4_full_size(pta, oracle, ps5_scene):
+    """BASELINE config 4 at its stated size: PS5 stand-in, 1920x1080, 512 spp, 8 bounces, FILMIC - 1.06 G work items,
+    i.e. four queue chunks per frame on the real scene.  Full frame on one GPU, then the eight tile shards of the
+    8-GPU job one after the other (each must reproduce its pixels of the full frame bit for bit), oracle rows."""
     scene, g = ps5_scene
-    prof = pta.Profile.make(1920, 1080, 131, 8, "FILMIC")
-    opts = pta.Opts.make(shard_rank=5, shard_count=8, tile_w=32, tile_h=32)   # one rank of the 8-GPU job
-    idx = pta.local_pixel_map(prof, opts)
-    rgb, acc = g.render(prof, opts)
-    osc = oracle.OracleScene(scene.desc, oracle.PTO_BVH)
-    for y in (300, 700):   # the rank's pixels of two rows, from the oracle's full rows
-        begin = y * prof.width
-        o_rgb, o_acc, _ = osc.render(prof, begin, begin + prof.width)
-        mine = np.nonzero((idx >= begin) & (idx < begin + prof.width))[0]
-        assert len(mine) > 0
-        assert np.array_equal(bits(o_acc[idx[mine] - begin]), bits(acc[mine]))
-        assert np.array_equal(o_rgb[idx[mine] - begin], rgb[mine])
+    prof = pta.Profile.make(1920, 1080, 512, 8, "FILMIC")
+    rgb, acc = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_TIMING))
+    assert g.timing().as_dict()["stage_launches"] > 4 * 3 * 9        # four chunks of nine bounce levels
+    assert np.isfinite(acc).all() and rgb.max() > 0
+    _oracle_rows_equal(pta, oracle, scene, prof, acc, rgb, (300, 700))
+    seen = np.zeros(prof.width * prof.height, bool)
+    for rank in range(8):
+        opts = pta.Opts.make(shard_rank=rank, shard_count=8, tile_w=32, tile_h=32)
+        idx = pta.local_pixel_map(prof, opts)
+        r_rgb, r_acc = g.render(prof, opts)
+        assert np.array_equal(bits(r_acc), bits(acc[idx])) and np.array_equal(r_rgb, rgb[idx]), rank
+        seen[idx] = True
+    assert seen.all()
+    # the KD-only path (the RNG planes of chunk c+1 are produced on a side stream underneath chunk c) gives the same frame
+    rgb_kd, acc_kd = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_NO_GRIDS))
+    assert np.array_equal(bits(acc_kd), bits(acc)) and np.array_equal(rgb_kd, rgb)
 
 
-def test_config5_translucent_4k(pta, oracle):
-    """BASELINE config 5's ingredients at full resolution: 3840x2160, translucent shells (opacity factor +
-    checker opacity texture: alpha walk with RNG draws, ordered shadow attenuation), 8 bounces, ACES.  The
-    triangle count (1 M instead of 4 M) and the sample count (8 instead of 1024) are reduced for test time;
-    neither enters the arithmetic of a sample."""
-    scene = pta.HostScene.generate_ps5(1000000, seed=0, flags=1)
+def test_config5_full_size(pta, oracle):
+    """BASELINE config 5 at its stated size: 3840x2160, 1024 spp, 8 bounces, ACES, the stand-in at 4 M triangles with
+    translucent shells (opacity factor 0.5 + 1024^2 checker opacity texture: alpha walk with RNG draws, ordered shadow
+    attenuation) - 8.5 G path samples.  Oracle rows of the very frame, counter identities, one shard of the 8-GPU job."""
+    scene = pta.HostScene.generate_ps5(4000000, seed=0, flags=1)
+    assert scene.n_triangles > 3900000
     g = pta.GpuScene(scene)
     assert g.info().has_translucent == 1
-    prof = pta.Profile.make(3840, 2160, 8, 8, "ACES")
-    rgb, acc = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS))
-    c = g.counters().as_dict()
-    assert c["samples"] == prof.width * prof.height * prof.samples and c["restarts"] > 0
-    _oracle_rows_equal(pta, oracle, scene, prof, acc, rgb, (700, 1080, 1500))
+    prof = pta.Profile.make(3840, 2160, 1024, 8, "ACES")
+    rgb, acc = g.render(prof)
+    assert np.isfinite(acc).all() and rgb.max() > 0
+    _oracle_rows_equal(pta, oracle, scene, prof, acc, rgb, (700, 1500))
     opts = pta.Opts.make(shard_rank=2, shard_count=8, tile_w=32, tile_h=32)
     idx = pta.local_pixel_map(prof, opts)
     r_rgb, r_acc = g.render(prof, opts)
     assert np.array_equal(bits(r_acc), bits(acc[idx])) and np.array_equal(r_rgb, rgb[idx])
+    # counters on a quarter of the samples of one shard (the instrumented kernels are slower)
+    prof_c = pta.Profile.make(3840, 2160, 32, 8, "ACES")
+    g.render(prof_c, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS, shard_rank=2, shard_count=8, tile_w=32, tile_h=32))
+    c = g.counters().as_dict()
+    assert c["samples"] == len(idx) * 32 and c["restarts"] > 0 and c["segments"] >= c["samples"]
+    # every shaded surface asks every light once; the alpha walk evaluates at least one surface per shaded one
+    assert 0 < c["shadow_rays"] <= c["shaded_hits"] * scene.n_lights and c["shadow_skipped"] <= c["shadow_rays"]
 
 
 @pytest.mark.parametrize("name", ["cube", "alpha_transparency"])

@@ -240,3 +240,34 @@ def test_png_with_a_lying_header_is_rejected(pta, tmp_path):
     w, h, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
     rc = lib.pth_png_decode(bytes(data), len(data), 3, C.byref(w), C.byref(h), C.byref(px))
     assert rc != 0 and b"cannot hold" in lib.pth_last_error()
+
+
+def test_textured_scene_survives_the_isf_round_trip(pta, oracle, tmp_path):
+    """Generator flag bit 1: normal map + emissive / metalness / roughness / albedo textures.  Written as ISF + PNG
+    files and loaded back (isf.rs serde model, texture_bank.rs into_rgb8 / into_luma8), the scene must render to the
+    same bits with the oracle - the loader and the oracle's texture paths (material.rs:132-214, hit.rs:55-82) agree."""
+    import numpy as np
+    scene = pta.HostScene.generate_ps5(6000, seed=0, flags=3)
+    d = scene.desc.contents
+    kinds = set()
+    for i in range(d.n_materials):
+        m = d.materials[i]
+        kinds |= {k for k in ("tex_albedo", "tex_emissive", "tex_opacity", "tex_metalness", "tex_roughness", "tex_normal")
+                  if getattr(m, k) >= 0}
+    assert len(kinds) == 6
+    scene.save_isf(tmp_path / "textured")
+    loaded = pta.HostScene.load_isf(tmp_path / "textured" / "scene.isf")
+    prof = pta.Profile.make(96, 54, 3, 4, "ACES")
+    rgb_a, acc_a, st_a = oracle.OracleScene(scene.desc, oracle.PTO_BVH).render(prof)
+    rgb_b, acc_b, st_b = oracle.OracleScene(loaded.desc, oracle.PTO_BVH).render(prof)
+    assert st_a == st_b and st_a["numeric_errors"] == 0
+    assert np.array_equal(acc_a.view(np.uint32), acc_b.view(np.uint32)) and np.array_equal(rgb_a, rgb_b)
+    # the oracle's G-buffer shows the maps: bumps in the normals, stripes in the metalness, dots in the emissive plane
+    planes = oracle.OracleScene(loaded.desc, oracle.PTO_BVH).debug_render(160, 90)
+    assert len(np.unique(planes["normal"].reshape(-1, 3), axis=0)) > 200
+    assert len(np.unique(planes["metalness"])) >= 3 and len(np.unique(planes["roughness"])) > 20
+    assert planes["emissive"].any()
+    # and the textures change the image
+    plain = pta.HostScene.generate_ps5(6000, seed=0, flags=1)
+    rgb_p, _, _ = oracle.OracleScene(plain.desc, oracle.PTO_BVH).render(prof)
+    assert not np.array_equal(rgb_p, rgb_a)

@@ -69,10 +69,34 @@ def test_moller_trumbore_miss_vectors(oracle):
 
 
 def test_rng_known_answers(oracle):
-    """StdRng::seed_from_u64(0): first two words as LE u64 = 5029875928683246316 is the
-    PCG32 *key* check of SURVEY §8-a0; the ChaCha12 stream itself is pinned by the hashes."""
+    """SURVEY 8-a0 check values.  (1) StdRng::seed_from_u64(0): the PCG32 expansion gives a key whose first two words,
+    read as a little-endian u64, are 5029875928683246316.  (2) The block function with 20 rounds and a zero key is
+    RFC 7539's ChaCha20: its keystream starts ade0b876 903df1a0 e56a5d40 28bd8653.  (3) The stream next_u32()
+    delivers is the 12-round block function over that key, block after block (pinned end to end by the hashes)."""
+    key = oracle.rng_key(0)
+    assert (int(key[1]) << 32) | int(key[0]) == 5029875928683246316
+    zero = oracle.chacha_block(np.zeros(8, np.uint32), 0, 20)
+    assert [f"{int(w):08x}" for w in zero[:4]] == ["ade0b876", "903df1a0", "e56a5d40", "28bd8653"]
     w = oracle.rng_words(np.array([0, 1, 2**63], np.uint64), 40)
     assert w.shape == (3, 40)
     assert len({tuple(r) for r in w}) == 3
-    # words 16.. come from the second block (counter = 1) and differ from the first block
-    assert not np.array_equal(w[:, :16], w[:, 16:32])
+    for row, seed in zip(w, (0, 1, 2**63)):
+        k = oracle.rng_key(seed)
+        assert np.array_equal(row[:16], oracle.chacha_block(k, 0, 12))
+        assert np.array_equal(row[16:32], oracle.chacha_block(k, 1, 12))   # counter = 1
+        assert not np.array_equal(row[:16], oracle.chacha_block(k, 0, 20))
+
+
+def test_partial_render_is_the_viewer_feed(pta, oracle, scene_cache):
+    """pto_render_partial: the first k passes of an N-sample render (seed stride N), post-processed with 1 / k."""
+    osc = oracle.OracleScene(scene_cache("cube").desc, oracle.PTO_BVH)
+    prof = pta.Profile.make(48, 32, 6, 2)
+    rgb_full, acc_full, _ = osc.render(prof)
+    rgb_all, acc_all, _ = osc.render(prof, sample_count=6)
+    assert np.array_equal(rgb_full, rgb_all) and np.array_equal(acc_full.view(np.uint32), acc_all.view(np.uint32))
+    rgb3, acc3, st = osc.render(prof, sample_count=3)
+    assert st["samples"] == 48 * 32 * 3
+    assert np.array_equal(oracle.post_process(pta.Profile.make(48, 32, 3, 2), acc3), rgb3)
+    # a 3-sample PROFILE uses another seed stride: different samples
+    _, acc_other, _ = osc.render(pta.Profile.make(48, 32, 3, 2))
+    assert not np.array_equal(acc_other.view(np.uint32), acc3.view(np.uint32))
