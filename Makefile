@@ -41,7 +41,7 @@ $(BUILD)/gpu/%.o: $(PKG)/csrc/%.hip $(GPU_HDR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(PKG)/libptgpu.so: $(GPU_OBJ) $(HOST_OBJ)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(GPU_OBJ) $(HOST_OBJ) -lz -pthread
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(GPU_OBJ) $(HOST_OBJ) -lz -pthread -ldl
 
 $(PKG)/path-tracer: $(PKG)/host/cli_main.cpp $(PKG)/libptgpu.so
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG) -lptgpu -Wl,-rpath,'$$ORIGIN'

@@ -191,6 +191,13 @@ typedef struct pt_scene pt_scene;
 int pt_scene_create(const pt_scene_desc* desc, int device, pt_scene** out);
 void pt_scene_destroy(pt_scene* scene);
 
+/* The host half of pt_scene_create (validation, KD build, origin grids) as an object of its own: build it ONCE
+ * and upload it to every device of a multi-GPU render instead of repeating seconds of CPU work per device. */
+typedef struct pt_prep pt_prep;
+int pt_prep_create(const pt_scene_desc* desc, pt_prep** out);
+void pt_prep_destroy(pt_prep* prep);
+int pt_scene_create_from_prep(const pt_prep* prep, int device, pt_scene** out);
+
 /* Number of pixels pt_render writes for (profile, opts). */
 uint64_t pt_local_pixel_count(const pt_profile* profile, const pt_opts* opts);
 /* local packed index -> global pixel index i = x + y*W; out has
@@ -218,6 +225,31 @@ int pt_render_device(const pt_scene* scene, const pt_profile* profile, const pt_
 int pt_assemble_tiles(const pt_profile* profile, uint32_t shard_count, uint32_t tile_w,
                       uint32_t tile_h, uint64_t slice_pixels, uint32_t elem_bytes,
                       const void* d_gathered, void* d_image, void* hip_stream);
+
+/* The exchange step of a multi-GPU render inside the library: one RCCL ncclAllGather over xGMI of
+ * the packed, zero-padded u8 (or f32) framebuffer slices + the scatter of pt_assemble_tiles, on `hip_stream`.
+ * Communicators: one process per GPU - rank 0 calls pt_comm_unique_id, the host's own bootstrap (MPI, a TCP
+ * store, torch.distributed) hands the 128 bytes to the other ranks, every rank calls pt_comm_create; one process
+ * driving several GPUs - pt_comm_create_all (ncclCommInitAll; `out` receives n handles, devices must be distinct).
+ * librccl.so is loaded on first use.  The reference has no counterpart (single process, rayon). */
+enum { PT_COMM_ID_BYTES = 128 };
+typedef struct pt_comm pt_comm;
+int pt_comm_unique_id(uint8_t id[PT_COMM_ID_BYTES]);
+int pt_comm_create(const uint8_t id[PT_COMM_ID_BYTES], int rank, int size, int device, pt_comm** out);
+int pt_comm_create_all(const int* devices, int n, pt_comm** out);
+void pt_comm_destroy(pt_comm* comm);
+/* d_local: this rank's slice_pixels * elem_bytes packed slice; d_gathered: scratch of size * that; d_image: the
+ * row-major W*H*elem_bytes frame, complete on every rank when the stream has drained.  Device pointers. */
+int pt_gather_tiles(pt_comm* comm, const pt_profile* profile, uint32_t tile_w, uint32_t tile_h,
+                    uint64_t slice_pixels, uint32_t elem_bytes, const void* d_local, void* d_gathered,
+                    void* d_image, void* hip_stream);
+
+/* Renderer::render on this rank's shard + the gather, host-buffer form: renders (profile, opts) on the device,
+ * all-gathers the slices (slice_pixels = the largest pt_local_pixel_count of any rank) and, when rgb8_frame is not
+ * NULL, copies the complete row-major RGB8 frame (W*H*3 bytes) to the host.  Every rank of the communicator must
+ * call it; opts->shard_rank / shard_count must be the communicator's rank / size. */
+int pt_render_gathered(const pt_scene* scene, pt_comm* comm, const pt_profile* profile, const pt_opts* opts,
+                       uint64_t slice_pixels, uint8_t* rgb8_frame);
 
 /* `--debug-textures` (src/renderer/debug_renderer.rs:11-105): one pixel-centre primary ray per
  * pixel, first entry of ray_cast() only, seven RGB8 planes of width*height*3 bytes each, in this

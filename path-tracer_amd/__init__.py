@@ -169,7 +169,8 @@ HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_s
                 "pth_png_decode", "pth_png_write_rgb8", "pth_free", "pth_prim_count", "pth_kd_build",
                 "pth_kd_free", "pth_origin_grid_build", "pth_origin_grid_free", "pth_last_error"]
 # Every symbol include/ptgpu.h declares.
-GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_local_pixel_count", "pt_local_pixel_map",
+GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_prep_create", "pt_prep_destroy", "pt_scene_create_from_prep",
+               "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_gather_tiles", "pt_render_gathered", "pt_local_pixel_count", "pt_local_pixel_map",
                "pt_render", "pt_render_device", "pt_debug_render", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
                "pt_scene_get_info", "pt_trace_rays", "pt_trace_rays_all", "pt_intersect_triangles",
                "pt_rng_words", "pt_eval_math", "pt_measure_copy_bandwidth", "pt_measure_gather_rate", "pt_last_error",
@@ -227,6 +228,17 @@ def gpu_lib():
         L.pt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(vp)]
         L.pt_scene_destroy.argtypes = [vp]
         L.pt_scene_destroy.restype = None
+        L.pt_prep_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
+        L.pt_prep_destroy.argtypes = [vp]
+        L.pt_prep_destroy.restype = None
+        L.pt_scene_create_from_prep.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.pt_comm_unique_id.argtypes = [vp]
+        L.pt_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.pt_comm_create_all.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+        L.pt_comm_destroy.argtypes = [vp]
+        L.pt_comm_destroy.restype = None
+        L.pt_gather_tiles.argtypes = [vp, C.POINTER(Profile), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, vp, vp]
+        L.pt_render_gathered.argtypes = [vp, vp, C.POINTER(Profile), C.POINTER(Opts), C.c_uint64, vp]
         L.pt_local_pixel_count.argtypes = [C.POINTER(Profile), C.POINTER(Opts)]
         L.pt_local_pixel_count.restype = C.c_uint64
         L.pt_local_pixel_map.argtypes = [C.POINTER(Profile), C.POINTER(Opts), vp]
@@ -371,14 +383,68 @@ def load_profile(path=None, text=None):
     return p
 
 
+class Prep:
+    """pt_prep: the host half of pt_scene_create (KD-tree, origin grids), built once for several devices."""
+
+    def __init__(self, host_scene: HostScene):
+        self.handle = C.c_void_p()
+        self._host = host_scene
+        check_gpu(gpu_lib().pt_prep_create(host_scene.desc, C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            gpu_lib().pt_prep_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """pt_comm: RCCL communicator of the tile gather (one process per GPU: unique id from rank 0)."""
+
+    def __init__(self, unique_id: bytes, rank, size, device):
+        self.handle = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check_gpu(gpu_lib().pt_comm_create(buf, rank, size, device, C.byref(self.handle)))
+        self.rank, self.size = rank, size
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        check_gpu(gpu_lib().pt_comm_unique_id(buf))
+        return bytes(buf)
+
+    def gather_tiles(self, profile, tile_w, tile_h, slice_pixels, elem_bytes, d_local, d_gathered, d_image, stream=0):
+        check_gpu(gpu_lib().pt_gather_tiles(self.handle, C.byref(profile), tile_w, tile_h, slice_pixels, elem_bytes,
+                                            d_local, d_gathered, d_image, stream))
+
+    def close(self):
+        if self.handle:
+            gpu_lib().pt_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GpuScene:
     """Device-resident scene (pt_scene_create / pt_scene_destroy)."""
 
-    def __init__(self, host_scene: HostScene, device=0):
+    def __init__(self, host_scene: HostScene, device=0, prep=None):
         self.lib = gpu_lib()
         self.handle = C.c_void_p()
         self._host = host_scene
-        check_gpu(self.lib.pt_scene_create(host_scene.desc, device, C.byref(self.handle)))
+        if prep is not None:   # host work (KD-tree, origin grids) done once by Prep, uploaded here
+            check_gpu(self.lib.pt_scene_create_from_prep(prep.handle, device, C.byref(self.handle)))
+        else:
+            check_gpu(self.lib.pt_scene_create(host_scene.desc, device, C.byref(self.handle)))
 
     def info(self):
         i = SceneInfo()

@@ -17,6 +17,8 @@
 //   k_trace / k_trace_all / k_isect / k_rng / k_math   parity-test hooks
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -488,12 +490,37 @@ void select_device(int device) {
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
 }
 
-void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
-    select_device(device);
-    int cur = 0;
-    HIP_CHECK(hipGetDevice(&cur));
-    s.device = cur;
+}  // namespace
 
+// Everything pt_scene_create computes on the HOST: validated copies of the small tables, the KD-tree in device
+// layout, the per-primitive arrays, the origin grids.  Built once per process and uploaded to as many devices as
+// the caller renders on (the CLI's --devices, a multi-GPU host): the KD build and the grid builds are seconds of
+// CPU work that do not depend on the device.
+struct pt_prep {
+    std::vector<pth_kd_node> nodes;            // treelet order (see below)
+    std::vector<float4> leaf, attr, pos;
+    std::vector<pt_material> model_mat;
+    std::vector<pt_texture> textures;
+    std::vector<uint8_t> texels;
+    std::vector<DevLight> lights;
+    float lut[256];
+    DevScene dev{};                            // scalars filled in; pointers are set per device
+    pt_scene_info info{};
+    struct Grid {
+        pth_origin_grid g{};
+        Grid() = default;
+        Grid(const Grid&) = delete;
+        Grid& operator=(const Grid&) = delete;
+        ~Grid() { pth_origin_grid_free(&g); }
+    };
+    std::unique_ptr<Grid> cam_grid;
+    std::vector<std::unique_ptr<Grid>> light_grids;
+    bool all_lights_gridded = false;
+};
+
+namespace {
+
+void prep_create(const pt_scene_desc& d, pt_prep& P) {
     // ---- validate
     for (uint32_t m = 0; m < d.n_models; ++m) {
         const pt_model& mo = d.models[m];
@@ -521,18 +548,19 @@ void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
     if (pth_kd_build(&d, &kd) != PT_OK) fail(PT_ERR_INVALID, "KD build failed: %s", pth_last_error());
     std::unique_ptr<pth_kdtree, void (*)(pth_kdtree*)> kd_guard(&kd, pth_kd_free);
     if (kd.depth >= PT_KD_STACK) fail(PT_ERR_UNSUPPORTED, "KD-tree depth %u exceeds the traversal stack", kd.depth);
-    auto t_up = std::chrono::steady_clock::now();
 
     // ---- per-primitive arrays
     uint64_t n_prims = pth_prim_count(&d);
-    std::vector<float4> attr(n_prims * 4), pos(n_prims * 3);
-    std::vector<pt_material> model_mat(d.n_models);
+    std::vector<float4>&attr = P.attr, &pos = P.pos;
+    attr.resize(n_prims * 4);
+    pos.resize(n_prims * 3);
+    P.model_mat.resize(d.n_models);
     bool translucent = false;
     uint64_t prim = 0;
     for (uint32_t m = 0; m < d.n_models; ++m) {
         const pt_model& mo = d.models[m];
-        model_mat[m] = d.materials[mo.material];
-        if (model_mat[m].opacity != 1.0f || model_mat[m].tex_opacity >= 0) translucent = true;
+        P.model_mat[m] = d.materials[mo.material];
+        if (P.model_mat[m].opacity != 1.0f || P.model_mat[m].tex_opacity >= 0) translucent = true;
         float mbits;
         memcpy(&mbits, &m, 4);
         if (mo.kind == PT_MODEL_MESH) {
@@ -566,25 +594,26 @@ void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
         }
     }
     // leaf records in leaf-reference order
-    std::vector<float4> leaf(kd.n_refs * 3);
+    P.leaf.resize(kd.n_refs * 3);
     for (uint64_t r = 0; r < kd.n_refs; ++r) {
         uint32_t p = kd.refs[r];
-        leaf[r * 3 + 0] = pos[(size_t)p * 3 + 0];
-        leaf[r * 3 + 1] = pos[(size_t)p * 3 + 1];
-        leaf[r * 3 + 2] = pos[(size_t)p * 3 + 2];
+        P.leaf[r * 3 + 0] = pos[(size_t)p * 3 + 0];
+        P.leaf[r * 3 + 1] = pos[(size_t)p * 3 + 1];
+        P.leaf[r * 3 + 2] = pos[(size_t)p * 3 + 2];
     }
     // sRGB -> linear table: (c as f32 / 255.0).powf(2.2) with the host libm (material.rs:137-141)
-    float lut[256];
-    for (int c = 0; c < 256; ++c) lut[c] = powf((float)c / 255.0f, 2.2f);
-    std::vector<DevLight> lights(d.n_lights);
+    for (int c = 0; c < 256; ++c) P.lut[c] = powf((float)c / 255.0f, 2.2f);
+    P.lights.resize(d.n_lights);
     for (uint32_t i = 0; i < d.n_lights; ++i) {
-        lights[i].kind = d.lights[i].kind;
-        memcpy(lights[i].vec, d.lights[i].vec, 12);
-        memcpy(lights[i].color, d.lights[i].color, 12);
-        lights[i].tame = 1u;
+        P.lights[i].kind = d.lights[i].kind;
+        memcpy(P.lights[i].vec, d.lights[i].vec, 12);
+        memcpy(P.lights[i].color, d.lights[i].color, 12);
+        P.lights[i].tame = 1u;
         for (int k = 0; k < 3; ++k)
-            if (!(fabsf(d.lights[i].color[k]) < 1e30f)) lights[i].tame = 0u;  // also catches NaN
+            if (!(fabsf(d.lights[i].color[k]) < 1e30f)) P.lights[i].tame = 0u;  // also catches NaN
     }
+    P.textures.assign(d.textures, d.textures + d.n_textures);
+    P.texels.assign(d.texels, d.texels + d.n_texel_bytes);
 
     // ---- device node layout.  The builder emits DFS order (below child = next node); on the GPU the
     // walk is bound by cache-line round trips (a wave waits for the slowest of ~43 scattered node
@@ -592,7 +621,8 @@ void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
     // node = pair, pair + 1) and the pairs of a 4-level subtree are packed consecutively, so that
     // one 128-byte line serves up to four steps of a walk.  Node words: interior (split,
     // pair << 2 | axis), leaf (first record, n << 2 | 3) as before.
-    std::vector<pth_kd_node> tre(std::max<uint64_t>(kd.n_nodes, 1) + 1);
+    std::vector<pth_kd_node>& tre = P.nodes;
+    tre.assign(std::max<uint64_t>(kd.n_nodes, 1) + 1, pth_kd_node{0u, 0u});
     {
         const pth_kd_node* N = kd.nodes;
         const int H = 4;  // treelet height: 2 + 4 + 8 = 14 nodes = 112 B below the treelet root pair
@@ -633,16 +663,7 @@ void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
             tre[1] = pth_kd_node{0u, 3u};
         }
     }
-    DevScene& D = s.dev;
-    D.kd_nodes = (const uint2*)s.upload(tre.data(), tre.size());
-    D.leaf_prims = s.upload(leaf.data(), leaf.size());
-    D.prim_attr = s.upload(attr.data(), attr.size());
-    D.prim_pos = s.upload(pos.data(), pos.size());
-    D.materials = s.upload(model_mat.data(), model_mat.size());
-    D.textures = s.upload(d.textures, d.n_textures);
-    D.texels = s.upload(d.texels, d.n_texel_bytes);
-    D.srgb_lut = s.upload(lut, 256);
-    D.lights = s.upload(lights.data(), lights.size());
+    DevScene& D = P.dev;
     D.n_lights = d.n_lights;
     D.n_prims = (uint32_t)n_prims;
     D.n_nodes = (uint32_t)kd.n_nodes;
@@ -668,59 +689,86 @@ void scene_create(const pt_scene_desc& d, int device, pt_scene& s) {
             const char* e = getenv("PT_OG");
             return !(e && *e && atoi(e) == 0);
         }();
-        auto upload_grid = [&](pth_origin_grid& g, DevGrid& out) {
-            std::unique_ptr<pth_origin_grid, void (*)(pth_origin_grid*)> guard(&g, pth_origin_grid_free);
-            memset(&out, 0, sizeof out);
-            if (!g.enabled) return;
-            out.cell_off = s.upload(g.cell_off, g.n_cells + 1);
-            out.refs = (const uint2*)s.upload(g.refs, std::max<uint64_t>(1, g.n_refs));
-            out.res = g.res;
-            out.n_global = g.n_global;
-            out.half_res = 0.5f * (float)g.res;
-            s.info.grid_refs += g.n_refs;
-        };
-        memset(&D.cam_grid, 0, sizeof D.cam_grid);
         // longest camera-ray direction: |M dir| <= ||M||_F for the unit vector dir (mod.rs:122-123)
         double fro = 0;
         for (int k = 0; k < 3; ++k)
             for (int r = 0; r < 3; ++r) fro += (double)M[4 * k + r] * M[4 * k + r];
         fro = std::sqrt(fro);
         if (grids_on && n_prims > 0 && fro > 0 && fro < 64.0) {
-            pth_origin_grid g;
-            if (pth_origin_grid_build(&d, M + 12, 0, 0.f, (float)(fro * 1.001), &g) != PT_OK)
+            P.cam_grid = std::make_unique<pt_prep::Grid>();
+            if (pth_origin_grid_build(&d, M + 12, 0, 0.f, (float)(fro * 1.001), &P.cam_grid->g) != PT_OK)
                 fail(PT_ERR_INVALID, "origin grid (camera): %s", pth_last_error());
-            upload_grid(g, D.cam_grid);
-            s.info.cam_grid_res = D.cam_grid.res;
+            if (P.cam_grid->g.enabled) {
+                P.info.cam_grid_res = P.cam_grid->g.res;
+                P.info.grid_refs += P.cam_grid->g.n_refs;
+            }
         }
         // lights: the shadow queue is consumed by ONE kernel, so the grids serve the shadow rays only when every
         // light is a point light with a grid.  A shadow ray starts n * 1e-5 off the line through the light
         // (mod.rs:291,319): the grids' margin covers |n| <= 1.5, longer normals take the KD-tree per surface.
-        std::vector<DevGrid> lgrids(d.n_lights);
         bool all = grids_on && d.n_lights > 0 && n_prims > 0;
         for (uint32_t i = 0; i < d.n_lights && all; ++i)
             if (d.lights[i].kind != PT_LIGHT_POINT) all = false;
         const float max_normal = 1.5f;
         for (uint32_t i = 0; i < d.n_lights && all; ++i) {
-            pth_origin_grid g;
-            if (pth_origin_grid_build(&d, d.lights[i].vec, 0, 1.05e-5f * max_normal, 1.001f, &g) != PT_OK)
+            P.light_grids.push_back(std::make_unique<pt_prep::Grid>());
+            if (pth_origin_grid_build(&d, d.lights[i].vec, 0, 1.05e-5f * max_normal, 1.001f, &P.light_grids.back()->g) != PT_OK)
                 fail(PT_ERR_INVALID, "origin grid (light %u): %s", i, pth_last_error());
-            upload_grid(g, lgrids[i]);
-            if (!lgrids[i].res) all = false;
+            if (!P.light_grids.back()->g.enabled) all = false;
         }
-        D.light_grids = s.upload(lgrids.data(), lgrids.size());
+        if (!all) P.light_grids.clear();
+        for (auto& g : P.light_grids) P.info.grid_refs += g->g.n_refs;
+        P.all_lights_gridded = all;
         D.all_lights_gridded = all ? 1u : 0u;
         D.light_grid_max_normal2 = max_normal * max_normal;
-        s.info.light_grids = all ? d.n_lights : 0u;
-        s.info.grid_build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_grid).count();
+        P.info.light_grids = all ? d.n_lights : 0u;
+        P.info.grid_build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_grid).count();
     }
 
-    s.info.n_prims = n_prims;
-    s.info.n_kd_nodes = kd.n_nodes;
-    s.info.n_kd_leaves = kd.n_leaves;
-    s.info.n_leaf_refs = kd.n_refs;
-    s.info.kd_depth = kd.depth;
-    s.info.has_translucent = translucent;
-    s.info.kd_build_seconds = (float)kd.build_seconds;
+    P.info.n_prims = n_prims;
+    P.info.n_kd_nodes = kd.n_nodes;
+    P.info.n_kd_leaves = kd.n_leaves;
+    P.info.n_leaf_refs = kd.n_refs;
+    P.info.kd_depth = kd.depth;
+    P.info.has_translucent = translucent;
+    P.info.kd_build_seconds = (float)kd.build_seconds;
+}
+
+// Copy a prepared scene to `device`.
+void scene_upload(const pt_prep& P, int device, pt_scene& s) {
+    select_device(device);
+    int cur = 0;
+    HIP_CHECK(hipGetDevice(&cur));
+    s.device = cur;
+    auto t_up = std::chrono::steady_clock::now();
+    s.info = P.info;
+    s.info.device_bytes = 0;
+    DevScene& D = s.dev;
+    D = P.dev;
+    D.kd_nodes = (const uint2*)s.upload(P.nodes.data(), P.nodes.size());
+    D.leaf_prims = s.upload(P.leaf.data(), P.leaf.size());
+    D.prim_attr = s.upload(P.attr.data(), P.attr.size());
+    D.prim_pos = s.upload(P.pos.data(), P.pos.size());
+    D.materials = s.upload(P.model_mat.data(), P.model_mat.size());
+    D.textures = s.upload(P.textures.data(), P.textures.size());
+    D.texels = s.upload(P.texels.data(), P.texels.size());
+    D.srgb_lut = s.upload(P.lut, 256);
+    D.lights = s.upload(P.lights.data(), P.lights.size());
+    auto upload_grid = [&](const pth_origin_grid& g, DevGrid& out) {
+        memset(&out, 0, sizeof out);
+        if (!g.enabled) return;
+        out.cell_off = s.upload(g.cell_off, g.n_cells + 1);
+        out.refs = (const uint2*)s.upload(g.refs, std::max<uint64_t>(1, g.n_refs));
+        out.res = g.res;
+        out.n_global = g.n_global;
+        out.half_res = 0.5f * (float)g.res;
+    };
+    memset(&D.cam_grid, 0, sizeof D.cam_grid);
+    if (P.cam_grid) upload_grid(P.cam_grid->g, D.cam_grid);
+    std::vector<DevGrid> lgrids(P.lights.size());
+    for (auto& g : lgrids) memset(&g, 0, sizeof g);
+    for (size_t i = 0; i < P.light_grids.size(); ++i) upload_grid(P.light_grids[i]->g, lgrids[i]);
+    D.light_grids = s.upload(lgrids.data(), lgrids.size());
     s.info.upload_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_up).count();
 }
 
@@ -1215,8 +1263,30 @@ const char* pt_version(void) { return "path-tracer_amd 0.1 (gfx950)"; }
 int pt_scene_create(const pt_scene_desc* desc, int device, pt_scene** out) {
     return guarded([&] {
         if (!desc || !out) fail(PT_ERR_INVALID, "pt_scene_create: null argument");
+        pt_prep prep;
+        prep_create(*desc, prep);
         auto s = std::make_unique<pt_scene>();
-        scene_create(*desc, device, *s);
+        scene_upload(prep, device, *s);
+        *out = s.release();
+    });
+}
+
+int pt_prep_create(const pt_scene_desc* desc, pt_prep** out) {
+    return guarded([&] {
+        if (!desc || !out) fail(PT_ERR_INVALID, "pt_prep_create: null argument");
+        auto p = std::make_unique<pt_prep>();
+        prep_create(*desc, *p);
+        *out = p.release();
+    });
+}
+
+void pt_prep_destroy(pt_prep* prep) { delete prep; }
+
+int pt_scene_create_from_prep(const pt_prep* prep, int device, pt_scene** out) {
+    return guarded([&] {
+        if (!prep || !out) fail(PT_ERR_INVALID, "pt_scene_create_from_prep: null argument");
+        auto s = std::make_unique<pt_scene>();
+        scene_upload(*prep, device, *s);
         *out = s.release();
     });
 }
@@ -1354,6 +1424,150 @@ int pt_assemble_tiles(const pt_profile* profile, uint32_t shard_count, uint32_t 
                            (const uint8_t*)d_gathered, (uint8_t*)d_image, c.d, c.max_local, profile->width,
                            profile->height, on.shard_count, on.tile_w, on.tile_h, c.tiles_x, slice_pixels, elem_bytes);
         HIP_CHECK(hipGetLastError());
+    });
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ RCCL gather
+// librccl.so is loaded on first use: a single-GPU host never needs it.
+namespace {
+struct Rccl {
+    typedef struct { char internal[128]; } UniqueId;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    void* handle = nullptr;
+    std::string error;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) {
+            r.error = std::string("cannot load librccl.so: ") + dlerror();
+            return;
+        }
+        auto sym = [&](const char* n) {
+            void* p = dlsym(r.handle, n);
+            if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n;
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    });
+    if (!r.error.empty()) fail(PT_ERR_DEVICE, "%s", r.error.c_str());
+    return r;
+}
+#define RCCL_CHECK(expr)                                                                                           \
+    do {                                                                                                           \
+        int _e = (expr);                                                                                           \
+        if (_e != 0) fail(PT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+}  // namespace
+
+struct pt_comm {
+    void* comm = nullptr;
+    int rank = 0, size = 1, device = 0;
+};
+
+extern "C" {
+
+int pt_comm_unique_id(uint8_t id[PT_COMM_ID_BYTES]) {
+    return guarded([&] {
+        if (!id) fail(PT_ERR_INVALID, "pt_comm_unique_id: null argument");
+        static_assert(sizeof(Rccl::UniqueId) == PT_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+        Rccl::UniqueId u;
+        RCCL_CHECK(rccl().GetUniqueId(&u));
+        memcpy(id, &u, sizeof u);
+    });
+}
+
+int pt_comm_create(const uint8_t id[PT_COMM_ID_BYTES], int rank, int size, int device, pt_comm** out) {
+    return guarded([&] {
+        if (!id || !out || size < 1 || rank < 0 || rank >= size) fail(PT_ERR_INVALID, "pt_comm_create: bad argument");
+        select_device(device);
+        auto c = std::make_unique<pt_comm>();
+        HIP_CHECK(hipGetDevice(&c->device));
+        c->rank = rank;
+        c->size = size;
+        Rccl::UniqueId u;
+        memcpy(&u, id, sizeof u);
+        RCCL_CHECK(rccl().CommInitRank(&c->comm, size, u, rank));
+        *out = c.release();
+    });
+}
+
+int pt_comm_create_all(const int* devices, int n, pt_comm** out) {
+    return guarded([&] {
+        if (!devices || !out || n < 1) fail(PT_ERR_INVALID, "pt_comm_create_all: bad argument");
+        std::vector<void*> comms(n, nullptr);
+        RCCL_CHECK(rccl().CommInitAll(comms.data(), n, devices));
+        for (int i = 0; i < n; ++i) {
+            out[i] = new pt_comm;
+            out[i]->comm = comms[i];
+            out[i]->rank = i;
+            out[i]->size = n;
+            out[i]->device = devices[i];
+        }
+    });
+}
+
+void pt_comm_destroy(pt_comm* c) {
+    if (!c) return;
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)rccl().CommDestroy(c->comm);
+    }
+    delete c;
+}
+
+int pt_gather_tiles(pt_comm* comm, const pt_profile* profile, uint32_t tile_w, uint32_t tile_h, uint64_t slice_pixels,
+                    uint32_t elem_bytes, const void* d_local, void* d_gathered, void* d_image, void* hip_stream) {
+    return guarded([&] {
+        if (!comm || !profile || !d_local || !d_gathered || !d_image) fail(PT_ERR_INVALID, "pt_gather_tiles: null argument");
+        if (elem_bytes != 3 && elem_bytes != 12) fail(PT_ERR_INVALID, "pt_gather_tiles: elem_bytes must be 3 or 12");
+        HIP_CHECK(hipSetDevice(comm->device));
+        // one exchange step: every rank contributes its packed, zero-padded slice (ncclChar = 0)
+        RCCL_CHECK(rccl().AllGather(d_local, d_gathered, (size_t)slice_pixels * elem_bytes, 0 /* ncclChar */, comm->comm,
+                                    (hipStream_t)hip_stream));
+        int rc = pt_assemble_tiles(profile, (uint32_t)comm->size, tile_w, tile_h, slice_pixels, elem_bytes, d_gathered, d_image,
+                                   hip_stream);
+        if (rc != PT_OK) throw GpuError{rc, g_err};
+    });
+}
+
+int pt_render_gathered(const pt_scene* scene, pt_comm* comm, const pt_profile* profile, const pt_opts* opts,
+                       uint64_t slice_pixels, uint8_t* rgb8_frame) {
+    return guarded([&] {
+        if (!scene || !comm || !profile || !opts) fail(PT_ERR_INVALID, "pt_render_gathered: null argument");
+        if (opts->shard_count != (uint32_t)comm->size || opts->shard_rank != (uint32_t)comm->rank)
+            fail(PT_ERR_INVALID, "pt_render_gathered: opts shard %u/%u does not match communicator rank %d/%d", opts->shard_rank,
+                 opts->shard_count, comm->rank, comm->size);
+        HIP_CHECK(hipSetDevice(scene->device));
+        pt_opts o;
+        normalise_opts(*profile, opts, o);
+        const uint64_t n_local = make_tile_map(*profile, o, o.shard_rank).n_local;
+        if (n_local > slice_pixels) fail(PT_ERR_INVALID, "pt_render_gathered: slice_pixels too small");
+        const size_t npix = (size_t)profile->width * profile->height;
+        Staged<uint8_t> d_local(nullptr, slice_pixels * 3), d_gathered(nullptr, slice_pixels * 3 * comm->size), d_image(nullptr, npix * 3);
+        HIP_CHECK(hipMemset(d_local.d, 0, slice_pixels * 3));   // the padding of the slice
+        render_device(*scene, *profile, opts, d_local.d, nullptr, nullptr);
+        int rc = pt_gather_tiles(comm, profile, o.tile_w, o.tile_h, slice_pixels, 3, d_local.d, d_gathered.d, d_image.d, nullptr);
+        if (rc != PT_OK) throw GpuError{rc, g_err};
+        HIP_CHECK(hipDeviceSynchronize());
+        if (rgb8_frame) d_image.fetch(rgb8_frame, npix * 3);
     });
 }
 

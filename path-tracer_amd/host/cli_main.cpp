@@ -10,8 +10,8 @@
 // The render itself runs on the GPU through the C ABI of include/ptgpu.h;
 // there is no CPU fallback.  Extras (not in the reference): --device N,
 // --devices A,B,... (one host thread per GPU, each rendering its share of interleaved 32x32 tiles: the
-// sharding of SURVEY 8-e inside one process, assembled on the host), --stats (one JSON line with timings
-// on stderr).
+// sharding of SURVEY 8-e inside one process; the KD-tree and the origin grids are built once and uploaded to every
+// device, the slices are exchanged by one RCCL all-gather), --stats (one JSON line with timings on stderr).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -183,37 +183,64 @@ int run_render(int argc, char** argv) {
     }
 
     if (devices.size() > 1) {
-        // One host thread per GPU: scene + KD-tree per device, shard k of N = tiles k, k + N, ... (the global
-        // pixel index stays in the RNG seed, so the assembled image equals the single-GPU one bit for bit).
+        // One host thread per GPU.  The host work (KD-tree, origin grids) is done ONCE (pt_prep) and uploaded to every
+        // device; shard k of N = tiles k, k + N, ... (the global pixel index stays in the RNG seed, so the assembled
+        // image equals the single-GPU one bit for bit).  Distinct devices exchange their packed u8 slices with one
+        // RCCL all-gather over xGMI and scatter them on the device (pt_gather_tiles); a device list with repeats
+        // (several shards on one GPU: a rehearsal) is assembled on the host, RCCL does not allow duplicates.
         const uint32_t n = (uint32_t)devices.size();
+        pt_prep* prep = nullptr;
+        if (pt_prep_create(pth_scene_desc(hscene), &prep) != PT_OK) die(pt_last_error());
+        bool distinct = true;
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t j = i + 1; j < n; ++j)
+                if (devices[i] == devices[j]) distinct = false;
+        std::vector<pt_comm*> comms(n, nullptr);
+        if (distinct && pt_comm_create_all(devices.data(), (int)n, comms.data()) != PT_OK) die(pt_last_error());
+        uint64_t slice_pixels = 0;
+        std::vector<pt_opts> opts(n);
+        for (uint32_t k = 0; k < n; ++k) {
+            memset(&opts[k], 0, sizeof(pt_opts));
+            opts[k].device = devices[k];
+            opts[k].shard_rank = k;
+            opts[k].shard_count = n;
+            opts[k].tile_w = opts[k].tile_h = 32;
+            slice_pixels = std::max<uint64_t>(slice_pixels, pt_local_pixel_count(&profile, &opts[k]));
+        }
         std::vector<std::vector<uint8_t>> part(n);
         std::vector<std::vector<uint32_t>> map(n);
         std::vector<std::string> error(n);
+        std::vector<uint8_t> rgb((size_t)profile.width * profile.height * 3);
         auto worker = [&](uint32_t k) {
-            pt_opts o;
-            memset(&o, 0, sizeof o);
-            o.device = devices[k];
-            o.shard_rank = k;
-            o.shard_count = n;
-            o.tile_w = o.tile_h = 32;
-            uint64_t count = pt_local_pixel_count(&profile, &o);
-            map[k].resize(count);
-            part[k].resize(count * 3);
             pt_scene* sc = nullptr;
-            if (pt_local_pixel_map(&profile, &o, map[k].data()) != PT_OK ||
-                pt_scene_create(pth_scene_desc(hscene), devices[k], &sc) != PT_OK ||
-                pt_render(sc, &profile, &o, part[k].data(), nullptr) != PT_OK)
-                error[k] = pt_last_error();   // (the message is thread-local: read it on this thread)
+            auto check = [&](int rc) {   // (the message is thread-local: read it on this thread)
+                if (rc != PT_OK && error[k].empty()) error[k] = pt_last_error();
+                return rc == PT_OK;
+            };
+            if (check(pt_scene_create_from_prep(prep, devices[k], &sc))) {
+                if (distinct) {
+                    if (check(pt_render_gathered(sc, comms[k], &profile, &opts[k], slice_pixels, k == 0 ? rgb.data() : nullptr)))
+                        (void)0;
+                } else {
+                    uint64_t count = pt_local_pixel_count(&profile, &opts[k]);
+                    map[k].resize(count);
+                    part[k].resize(count * 3);
+                    if (check(pt_local_pixel_map(&profile, &opts[k], map[k].data())))
+                        check(pt_render(sc, &profile, &opts[k], part[k].data(), nullptr));
+                }
+            }
             if (sc) pt_scene_destroy(sc);
         };
         std::vector<std::thread> threads;
         for (uint32_t k = 0; k < n; ++k) threads.emplace_back(worker, k);
         for (auto& t : threads) t.join();
+        for (pt_comm* c : comms) pt_comm_destroy(c);
+        pt_prep_destroy(prep);
         for (uint32_t k = 0; k < n; ++k)
             if (!error[k].empty()) die(error[k]);
-        std::vector<uint8_t> rgb((size_t)profile.width * profile.height * 3);
-        for (uint32_t k = 0; k < n; ++k)
-            for (size_t i = 0; i < map[k].size(); ++i) memcpy(&rgb[(size_t)map[k][i] * 3], &part[k][i * 3], 3);
+        if (!distinct)
+            for (uint32_t k = 0; k < n; ++k)
+                for (size_t i = 0; i < map[k].size(); ++i) memcpy(&rgb[(size_t)map[k][i] * 3], &part[k][i * 3], 3);
         auto t3 = std::chrono::steady_clock::now();
         if (!quiet)
             fprintf(stderr, "Done: %llds\n", (long long)std::chrono::duration_cast<std::chrono::seconds>(t3 - t2).count());
@@ -224,8 +251,8 @@ int run_render(int argc, char** argv) {
         if (pth_png_write_rgb8(output.c_str(), profile.width, profile.height, rgb.data()) != PT_OK) die(pth_last_error());
         if (stats) {
             double sec = std::chrono::duration<double>(t3 - t2).count();
-            fprintf(stderr, "{\"devices\": %u, \"render_s\": %.3f, \"msamples_per_s\": %.2f}\n", n, sec,
-                    (double)profile.width * profile.height * profile.samples / sec / 1e6);
+            fprintf(stderr, "{\"devices\": %u, \"gather\": \"%s\", \"render_s\": %.3f, \"msamples_per_s\": %.2f}\n", n,
+                    distinct ? "rccl" : "host", sec, (double)profile.width * profile.height * profile.samples / sec / 1e6);
         }
         pth_scene_free(hscene);
         return 0;

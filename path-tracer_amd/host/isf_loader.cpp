@@ -150,7 +150,9 @@ public:
         return false;
     }
 
-    void skip_value() {
+    // (recursive: an ISF of a few hundred thousand nested '[' must end in PT_ERR_PARSE, not in a stack overflow)
+    void skip_value(int depth = 0) {
+        if (depth > 256) error("value nested too deeply");
         char c = peek();
         if (c == '{') {
             ++p_;
@@ -158,14 +160,14 @@ public:
             do {
                 string();
                 expect(':');
-                skip_value();
+                skip_value(depth + 1);
             } while (consume(','));
             expect('}');
         } else if (c == '[') {
             ++p_;
             if (consume(']')) return;
             do {
-                skip_value();
+                skip_value(depth + 1);
             } while (consume(','));
             expect(']');
         } else if (c == '"') {

@@ -12,23 +12,23 @@
 // inside a model) that also defines the reference's tie order.
 //
 // Robustness rules that keep the "never drop a hit" property:
-//   * primitives are assigned to children by their exact f32 AABB (no
-//     clipping): below = { min < split }, above = { max > split }, primitives
-//     lying IN the plane go to the cheaper side.  A primitive that merely touches the
-//     plane from one side is NOT duplicated (on tessellated meshes, where
-//     split planes sit on shared vertices, duplicating them multiplies the
-//     leaf references ~10x);
-//   * split positions are primitive AABB bounds (exact f32 values);
-//   * in exchange the device traversal visits BOTH children whenever the
-//     plane parameter lies within a relative epsilon of the node's ray
-//     interval, accepts hits outside the current leaf interval, and keeps
-//     walking while the next node starts before the best hit (plus slack),
-//     see csrc/pt_integrator.h kd_traverse().
+//   * "perfect splits": a primitive is assigned to a child by the bounds of (primitive ∩ node box) -
+//     triangles are clipped to the node box (Sutherland–Hodgman in f64, rounded outward), spheres keep
+//     their AABB; below = { clipped min < split }, above = { clipped max > split }, primitives lying IN
+//     the plane go to the cheaper side.  A primitive that merely touches the plane from one side is NOT
+//     duplicated (on tessellated meshes, where split planes sit on shared vertices, duplicating them
+//     multiplies the leaf references ~10x), and a plane ON the node boundary may peel planar primitives
+//     into a zero-thickness child (a ground plane on the scene-box face);
+//   * split positions are (clipped) primitive bounds: exact f32 values;
+//   * in exchange the device traversal visits BOTH children whenever the plane parameter lies within a
+//     relative epsilon of the node's ray interval, accepts hits outside the current leaf interval, and
+//     keeps walking while the next node starts before the best hit (plus slack), see
+//     csrc/pt_integrator.h kd_traverse() and csrc/pt_wavefront.h trav_step().
 //
-// Cost model: surface-area heuristic with exact sweep over AABB edges
-// (after Wald & Havran / pbrt's KdTreeAccel), traversal cost 1, empty bonus
-// 0.5; intersection cost and leaf size are tunable through PT_KD_ISECT_COST
-// / PT_KD_MAX_LEAF for experiments.
+// Cost model: surface-area heuristic with an exact sweep over the clipped bounds (after Wald & Havran /
+// pbrt's KdTreeAccel), traversal cost 1, intersection cost 24, empty-space bonus 0.2, leaves of at most 4,
+// depth cap 16 + 1.3 log2 n; all tunable through PT_KD_ISECT_COST / PT_KD_MAX_LEAF / PT_KD_EMPTY_BONUS /
+// PT_KD_MAX_DEPTH / PT_KD_CLIP for experiments (measured optima).
 #include <algorithm>
 #include <chrono>
 #include <cmath>

@@ -15,6 +15,7 @@
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <fstream>
 #include <vector>
 
@@ -129,7 +130,9 @@ void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32
         }
     }
 
-    uint8_t* out = (uint8_t*)malloc((size_t)w * h * want);
+    // (owned until the end: a malformed palette index below throws)
+    std::unique_ptr<uint8_t, void (*)(void*)> out_owner((uint8_t*)malloc((size_t)w * h * want), free);
+    uint8_t* out = out_owner.get();
     if (!out) throw std::bad_alloc();
     auto sample = [&](const uint8_t* row, size_t idx) -> uint32_t {  // idx = sample index in row
         if (depth == 8) return row[idx];
@@ -174,7 +177,7 @@ void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32
     }
     *ow = w;
     *oh = h;
-    *opx = out;
+    *opx = out_owner.release();
 }
 
 void put32(std::vector<uint8_t>& v, uint32_t x) {

@@ -271,3 +271,38 @@ def test_textured_scene_survives_the_isf_round_trip(pta, oracle, tmp_path):
     plain = pta.HostScene.generate_ps5(6000, seed=0, flags=1)
     rgb_p, _, _ = oracle.OracleScene(plain.desc, oracle.PTO_BVH).render(prof)
     assert not np.array_equal(rgb_p, rgb_a)
+
+
+def test_deeply_nested_json_is_a_parse_error_not_a_crash(pta, tmp_path):
+    """An unknown key whose value is a million nested arrays: the reader's recursion is bounded (PT_ERR_PARSE = -3)."""
+    deep = tmp_path / "deep.isf"
+    deep.write_text('{"junk":' + "[" * 1000000 + "]" * 1000000 + ',"models":[],"lights":[],"background":[0,0,0]}')
+    with pytest.raises(pta.PtError) as e:
+        pta.HostScene.load_isf(deep)
+    assert e.value.code == -3 and "nested too deeply" in str(e.value)
+    ok = tmp_path / "ok.isf"   # 200 levels are fine
+    cam = '{"transform":[[1,0,0,0],[0,1,0,0],[0,0,1,0],[0,0,4,1]],"fov":0.8,"zfar":100.0,"znear":0.1}'
+    ok.write_text('{"junk":' + "[" * 200 + "]" * 200 + f',"models":[],"camera":{cam},"lights":[],"background":[0,0,0]}}')
+    assert pta.HostScene.load_isf(ok).n_triangles == 0
+
+
+def test_bad_palette_png_does_not_leak(pta):
+    """A palette PNG whose pixels index past the palette: PT_ERR_PARSE, and the decoded-so-far buffer is released
+    (repeated many times the process does not grow)."""
+    import resource, struct, zlib
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
+    w = h = 512
+    raw = b"".join(b"\x00" + b"\x05" * w for _ in range(h))           # index 5 everywhere, palette has 2 entries
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 3, 0, 0, 0)) +
+           chunk(b"PLTE", bytes([0, 0, 0, 255, 255, 255])) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    import ctypes as C
+    lib = pta.host_lib()
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    for _ in range(400):                                               # 400 x 768 KiB would be 300 MiB if leaked
+        ww, hh, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+        rc = lib.pth_png_decode(png, len(png), 3, C.byref(ww), C.byref(hh), C.byref(px))
+        assert rc == -3 and b"palette" in lib.pth_last_error()
+    after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert after - before < 100 * 1024                                 # KiB
