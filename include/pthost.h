@@ -37,7 +37,9 @@ const pt_scene_desc* pth_scene_desc(const pth_scene* s);
  *                opacity texture (BASELINE cfg 5)
  *                bit1: procedural textures of every other kind: the shells get a
  *                normal map, metalness and roughness textures (one of them an
- *                albedo texture too), the core an emissive texture */
+ *                albedo texture too), the core an emissive texture
+ *                bit2: four walls and a ceiling close the scene into a room
+ *                (no path escapes: the bounce loop runs to its end) */
 int pth_scene_generate_ps5(uint64_t target_tris, uint64_t seed, uint32_t flags, pth_scene** out);
 
 /* Write a scene as ISF JSON (+ textures as PNG next to it). */

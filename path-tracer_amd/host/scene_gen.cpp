@@ -283,6 +283,21 @@ void generate(uint64_t target, uint64_t seed, uint32_t flags, pth_scene& sc) {
         end_mesh(sc, first);
     }
 
+    // 5. (flags bit 2) a closed room around everything: four walls and a ceiling on the edges of the ground
+    // quad - no path leaves into the background, so the bounce loop (mod.rs:180) runs to its end
+    if (flags & 4u) {
+        const uint32_t g = std::max(8u, g_ground / 4u);
+        begin_mesh(sc, plain(0.95f, 0.93f, 0.90f, 0.5f, 0.f), first);
+        const double H = 10.0, E = 12.0;
+        // (patch normals point INTO the room: cross(ds, dt) with the parametrisations below)
+        add_patch(sc, [=](double u, double v) { return V3{-E + 2 * E * u, H * v, -E}; }, g, g, false, rng, 0.0, 6.0, false);  // back  (+z)
+        add_patch(sc, [=](double u, double v) { return V3{E - 2 * E * u, H * v, E}; }, g, g, false, rng, 0.0, 6.0, false);   // front (-z)
+        add_patch(sc, [=](double u, double v) { return V3{-E, H * v, E - 2 * E * u}; }, g, g, false, rng, 0.0, 6.0, false);  // left  (+x)
+        add_patch(sc, [=](double u, double v) { return V3{E, H * v, -E + 2 * E * u}; }, g, g, false, rng, 0.0, 6.0, false);  // right (-x)
+        add_patch(sc, [=](double u, double v) { return V3{-E + 2 * E * u, H, -E + 2 * E * v}; }, g, g, false, rng, 0.0, 6.0, false);  // ceiling (-y)
+        end_mesh(sc, first);
+    }
+
     // light, camera, background
     pt_light l{};
     l.kind = PT_LIGHT_POINT;
