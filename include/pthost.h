@@ -1,8 +1,8 @@
 /*
  * pthost.h — host-side surface that "stays" either side of the hot path
  * (libpthost.so; no HIP dependency): the ISF scene loader, profile.yml
- * parser, PNG codec, the deterministic PS5 stand-in scene generator and the
- * KD-tree builder.  The `path-tracer` CLI, the tests and bench.py use it to
+ * parser, PNG codec, the glTF converter, the deterministic PS5 stand-in
+ * scene generator, the KD-tree builder and the origin-grid builder.  The `path-tracer` CLI, the tests and bench.py use it to
  * produce the flat pt_scene_desc that pt_scene_create() consumes.
  *
  * Reference counterparts:
@@ -11,6 +11,7 @@
  *   pth_profile_load     src/config/profile.rs:10-40, resolution.rs:3-16
  *   pth_png_*            image crate: open().into_rgb8()/into_luma8(), RgbImage::save
  *   pth_kd_build         kdtree-ray KDTree::build (internal/mod.rs:42, model.rs:96)
+ *   pth_convert_gltf     src/scene/gltf.rs:146-265 (convert_gltf_to_isf)
  */
 #ifndef PTHOST_H
 #define PTHOST_H
@@ -45,13 +46,18 @@ int pth_scene_generate_ps5(uint64_t target_tris, uint64_t seed, uint32_t flags, 
 /* Write a scene as ISF JSON (+ textures as PNG next to it). */
 int pth_scene_save_isf(const pth_scene* s, const char* dir);
 
+/* `convert <INPUT> <OUTPUT>` (src/scene/gltf.rs:146-265): glTF 2.0 (.gltf / .glb) -> OUTPUT/scene.isf + PNG
+ * textures; scene 0, first camera, KHR_lights_punctual lights (spot -> point, size 0.1). */
+int pth_convert_gltf(const char* input, const char* output_dir);
+
 /* profile.yml: every key optional; unknown keys ignored. path == NULL gives
  * Profile::default(). */
 int pth_profile_load(const char* path, pt_profile* out);
 int pth_profile_parse(const char* yaml_text, pt_profile* out);
 
-/* PNG. Decoded images are 8-bit; want_channels 1 (into_luma8) or 3
- * (into_rgb8). *pixels is malloc'd; free with pth_free. */
+/* PNG. Decoded images are 8-bit; want_channels 1 (into_luma8), 3
+ * (into_rgb8) or 4 (into_rgba8: the glTF converter splits base-colour
+ * textures into rgb + alpha). *pixels is malloc'd; free with pth_free. */
 int pth_png_read(const char* path, uint32_t want_channels, uint32_t* w, uint32_t* h,
                  uint8_t** pixels);
 int pth_png_decode(const uint8_t* data, size_t len, uint32_t want_channels, uint32_t* w,

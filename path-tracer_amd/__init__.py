@@ -165,7 +165,7 @@ _gpu = None
 
 # Every symbol include/pthost.h declares (tests check they are all exported).
 HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_scene_generate_ps5",
-                "pth_scene_save_isf", "pth_profile_load", "pth_profile_parse", "pth_png_read",
+                "pth_scene_save_isf", "pth_convert_gltf", "pth_profile_load", "pth_profile_parse", "pth_png_read",
                 "pth_png_decode", "pth_png_write_rgb8", "pth_free", "pth_prim_count", "pth_kd_build",
                 "pth_kd_free", "pth_origin_grid_build", "pth_origin_grid_free", "pth_last_error"]
 # Every symbol include/ptgpu.h declares.
@@ -192,6 +192,7 @@ def host_lib():
         L.pth_scene_desc.restype = C.POINTER(SceneDesc)
         L.pth_scene_generate_ps5.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p)]
         L.pth_scene_save_isf.argtypes = [C.c_void_p, C.c_char_p]
+        L.pth_convert_gltf.argtypes = [C.c_char_p, C.c_char_p]
         L.pth_profile_load.argtypes = [C.c_char_p, C.POINTER(Profile)]
         L.pth_profile_parse.argtypes = [C.c_char_p, C.POINTER(Profile)]
         L.pth_png_read.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
@@ -372,6 +373,11 @@ class OriginGrid:
             self.close()
         except Exception:
             pass
+
+
+def convert_gltf(input_path, output_dir):
+    """`path-tracer convert`: glTF 2.0 -> output_dir/scene.isf + textures (src/scene/gltf.rs:146-265)."""
+    check_host(host_lib().pth_convert_gltf(os.fsencode(str(input_path)), os.fsencode(str(output_dir))))
 
 
 def load_profile(path=None, text=None):

@@ -4,7 +4,7 @@
 //   path-tracer render <INPUT> [-o/--output <OUTPUT>] [-q/--quiet] [-v/--viewer]
 //                              [--debug-textures] [-p/--profile <PROFILE>]
 //       env OUTPUT (default render.png), env PROFILE
-//   path-tracer convert <INPUT> <OUTPUT>      (glTF -> ISF: out of scope)
+//   path-tracer convert <INPUT> <OUTPUT>      (glTF 2.0 -> ISF, host/gltf_convert.cpp)
 //
 // Any error prints the message on stderr and exits with code 2 (main.rs:14-22).
 // The render itself runs on the GPU through the C ABI of include/ptgpu.h;
@@ -311,6 +311,33 @@ int run_render(int argc, char** argv) {
     return 0;
 }
 
+// path-tracer convert <INPUT> <OUTPUT> (config/mod.rs:44-52, main.rs:54-57)
+int run_convert(int argc, char** argv) {
+    std::vector<std::string> pos;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-h" || a == "--help") {
+            fputs("Convert scenes into ISF format\n\n"
+                  "Usage: path-tracer convert <INPUT> <OUTPUT>\n\n"
+                  "Arguments:\n"
+                  "  <INPUT>   Input file name gltf format\n"
+                  "  <OUTPUT>  Output directory name\n\n"
+                  "Options:\n"
+                  "  -h, --help  Print help\n",
+                  stdout);
+            return 0;
+        }
+        if (a.size() > 1 && a[0] == '-') die("error: unexpected argument '" + a + "' found\n\nUsage: path-tracer convert <INPUT> <OUTPUT>");
+        pos.push_back(a);
+    }
+    if (pos.size() < 2)
+        die(std::string("error: the following required arguments were not provided:\n") + (pos.empty() ? "  <INPUT>\n" : "") +
+            "  <OUTPUT>\n\nUsage: path-tracer convert <INPUT> <OUTPUT>");
+    if (pos.size() > 2) die("error: unexpected argument '" + pos[2] + "' found\n\nUsage: path-tracer convert <INPUT> <OUTPUT>");
+    if (pth_convert_gltf(pos[0].c_str(), pos[1].c_str()) != PT_OK) die(pth_last_error());
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -320,8 +347,7 @@ int main(int argc, char** argv) {
     }
     std::string cmd = argv[1];
     if (cmd == "render") return run_render(argc - 2, argv + 2);
-    if (cmd == "convert") die("convert (glTF -> ISF) is outside the scope of this build: the render path consumes ISF "
-                              "files produced by the reference's converter (SURVEY §2 row 14)");
+    if (cmd == "convert") return run_convert(argc - 2, argv + 2);
     if (cmd == "-h" || cmd == "--help" || cmd == "help") {
         usage_main(stdout);
         return 0;

@@ -40,7 +40,7 @@ void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32
             uint8_t** opx) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
     if (len < 8 || memcmp(data, sig, 8) != 0) fail(PT_ERR_PARSE, "not a PNG file");
-    if (want != 1 && want != 3) fail(PT_ERR_INVALID, "want_channels must be 1 or 3");
+    if (want != 1 && want != 3 && want != 4) fail(PT_ERR_INVALID, "want_channels must be 1, 3 or 4");
     size_t pos = 8;
     uint32_t w = 0, h = 0;
     int depth = 0, ctype = -1, interlace = 0;
@@ -149,8 +149,10 @@ void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32
     for (uint32_t y = 0; y < h; ++y) {
         const uint8_t* row = raw.data() + (stride + 1) * (size_t)y + 1;
         for (uint32_t x = 0; x < w; ++x) {
-            uint8_t r, g, b;
+            uint8_t r, g, b, a = 255;
             bool is_gray = false;
+            if (ctype == 4) a = to8(sample(row, (size_t)x * channels + 1));
+            if (ctype == 6) a = to8(sample(row, (size_t)x * channels + 3));
             if (ctype == 0 || ctype == 4) {
                 r = g = b = to8(sample(row, (size_t)x * channels));
                 is_gray = true;
@@ -166,10 +168,11 @@ void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32
                 b = to8(sample(row, (size_t)x * channels + 2));
             }
             uint8_t* o = out + ((size_t)y * w + x) * want;
-            if (want == 3) {
+            if (want >= 3) {
                 o[0] = r;
                 o[1] = g;
                 o[2] = b;
+                if (want == 4) o[3] = a;   // (into_rgba8: opaque when the file has no alpha channel; tRNS is not read)
             } else {
                 o[0] = is_gray ? r : (uint8_t)((2126u * r + 7152u * g + 722u * b) / 10000u);
             }

@@ -357,7 +357,11 @@ void save_isf(const pth_scene& s, const std::string& dir) {
     std::vector<std::string> names(d.n_textures);
     for (uint32_t i = 0; i < d.n_textures; ++i) {
         const pt_texture& t = d.textures[i];
-        names[i] = "tex_" + std::to_string(i) + ".png";
+        // (the glTF converter names its textures like the reference's ReverseTextureBank, gltf.rs:47-76)
+        const std::string& given = i < s.texture_paths.size() ? s.texture_paths[i] : std::string();
+        const bool plain_png = given.size() > 4 && given.compare(given.size() - 4, 4, ".png") == 0 &&
+                               given.find('/') == std::string::npos && given.find(':') == std::string::npos;
+        names[i] = plain_png ? given : "tex_" + std::to_string(i) + ".png";
         std::vector<uint8_t> rgb((size_t)t.width * t.height * 3);
         const uint8_t* src = d.texels + t.offset;
         for (size_t p = 0; p < (size_t)t.width * t.height; ++p)
