@@ -124,4 +124,11 @@ struct DevCounters {
         restarts, max_nodes_per_cast, casts_over_1k_nodes, trace_nodes, trace_tris, shadow_skipped,
         bounce0_hits, bounce0_shadow_rays, bounce0_tris, grid_tris;
     unsigned long long stamps[8];  // diagnostic builds (-DWF_STAMPS) only
+#ifdef WF_EXIT_TIMES
+    // diagnostic build only: s_memrealtime (100 MHz) at the start of every k_wf_trace launch (minimum over
+    // workgroups) and at the exit of every wavefront, per launch (bounce): the shape of the drain phase
+    unsigned long long launch_start[8];
+    unsigned long long wave_exit[8][8192];
+    unsigned long long wave_queue_done[8][8192];   // when the wavefront found the queue exhausted
+#endif
 };

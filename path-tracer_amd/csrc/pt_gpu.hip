@@ -812,6 +812,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     if (counting) {
         s.counter_buf.ensure(sizeof(DevCounters));
         HIP_CHECK(hipMemsetAsync(s.counter_buf.p, 0, sizeof(DevCounters), stream));
+#ifdef WF_EXIT_TIMES
+        HIP_CHECK(hipMemsetAsync(&((DevCounters*)s.counter_buf.p)->launch_start, 0xff, sizeof(((DevCounters*)nullptr)->launch_start), stream));
+#endif
     }
 
     RenderParams P{};
@@ -999,6 +1002,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 W.n_items = std::min(cap, total_items - base);
                 W.cap = cap;
                 uint4* rng_planes = (uint4*)pipe.rng[rng_ahead ? (chunk_no & 1u) : 0u].p;
+                // coherence sorting of the survivors by direction octant: measured (MI355X, config 3) trace of bounce 1
+                // 9.50 -> 9.25 ms, but the bounce-0 kernel 19.0 -> 20.2 ms: off by default
+                static const uint32_t wf_sort = [] {
+                    const char* e = getenv("PT_WF_SORT");
+                    return (uint32_t)(e && *e ? atoi(e) : 0);
+                }();
+                W.sort_octants = wf_sort;
                 W.refill_min = std::max(1u, std::min(64u, wf_refill));
                 W.walk_steps = std::max(1u, wf_walk);
                 WfCounters* wctr = (WfCounters*)pipe.ctr.p;
@@ -1232,6 +1242,26 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                                  c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes,
                                  c.trace_nodes, c.trace_tris, c.shadow_skipped, c.bounce0_hits, c.bounce0_shadow_rays,
                                  c.bounce0_tris, c.grid_tris};
+#ifdef WF_EXIT_TIMES
+        {   // diagnostic build: when did the wavefronts of every k_wf_trace launch run out of queue / exit? (us after launch start)
+            std::unique_ptr<DevCounters> full(new DevCounters);
+            HIP_CHECK(hipMemcpy(full.get(), s.counter_buf.p, sizeof(DevCounters), hipMemcpyDeviceToHost));
+            for (int b = 0; b < 8; ++b) {
+                std::vector<double> ex, qd;
+                for (int w = 0; w < 8192; ++w)
+                    if (full->wave_exit[b][w]) {
+                        ex.push_back((double)(full->wave_exit[b][w] - full->launch_start[b]) / 100.0);
+                        if (full->wave_queue_done[b][w]) qd.push_back((double)(full->wave_queue_done[b][w] - full->launch_start[b]) / 100.0);
+                    }
+                if (ex.empty()) continue;
+                std::sort(ex.begin(), ex.end());
+                std::sort(qd.begin(), qd.end());
+                auto q = [](const std::vector<double>& v, double f) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+                fprintf(stderr, "[pt] trace bounce %d: %zu waves | queue exhausted (us) p1 %.0f p50 %.0f p99 %.0f max %.0f | exit p1 %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f\n",
+                        b, ex.size(), q(qd, 0.01), q(qd, 0.5), q(qd, 0.99), qd.empty() ? 0.0 : qd.back(), q(ex, 0.01), q(ex, 0.1), q(ex, 0.5), q(ex, 0.9), q(ex, 0.99), q(ex, 0.999), ex.back());
+            }
+        }
+#endif
         if (getenv("PT_DEBUG_STAMPS"))
             fprintf(stderr, "[pt] trace stamps: refill %llu walk %llu leaf %llu complete %llu cycles | walk lanes/step %.1f (%llu steps) | leaf lanes/run %.1f (%llu runs)\n",
                     c.stamps[0], c.stamps[1], c.stamps[2], c.stamps[3], c.stamps[5] ? (double)c.stamps[4] / c.stamps[5] : 0.0,

@@ -71,13 +71,20 @@ struct WfParams {
     uint32_t bounce;      // current bounce (shade / shadow)
     uint32_t refill_min;  // idle lanes that trigger a queue refill in the persistent kernels
     uint32_t walk_steps;  // node steps per walking phase
+    uint32_t sort_octants;  // k_wf_shade buckets the survivors of a workgroup step by direction octant
 };
 
+#ifndef WF_CURSORS
+#define WF_CURSORS 8u   // fetch cursors per queue (a power of two)
+#endif
+#define WF_CURSOR_STRIDE 32u   // words between two cursors (128 bytes)
 struct WfCounters {  // one set per bounce level, zeroed once per chunk
     uint32_t queue_count;    // records in queue[b]
     uint32_t shadow_count;   // records in the shadow queue of bounce b
-    uint32_t trace_work;     // dynamic fetch cursors
-    uint32_t shadow_work;
+    // dynamic fetch cursors (see wave_fetch): WF_CURSORS words per queue, each on a 128-byte line of its own (the
+    // memory-side atomic unit serialises per line, not per word: eight cursors in one line behaved like one)
+    uint32_t trace_work[WF_CURSORS * WF_CURSOR_STRIDE];
+    uint32_t shadow_work[WF_CURSORS * WF_CURSOR_STRIDE];
     uint32_t offgrid_count;  // shadow records k_og_shadow left to k_og_shadow_offgrid (pt_grid_kernels.h)
 };
 
@@ -108,13 +115,17 @@ PT_D uint32_t wf_reserve(uint32_t* counter, bool want) {
     return base + wf_lane_rank(m);
 }
 
-// Queue consumption for the persistent kernels.  One returning atomic on a single word
-// saturates at ~88 per microsecond on MI355X (MI355X_MICROARCH.md, "dequeue"), which a
-// per-refill atomic hits at a few hundred Mrays/s; so a wavefront reserves WF_CHUNK entries at a
-// time and hands them to its idle lanes from wave-uniform registers (ballot + mbcnt prefix).
-// The reservation shrinks with the queue (>= ~16 reservations per wavefront, 64 ... 512 entries): with 512 a
-// launch of a few million rays gave most waves one or two reservations of 8 rays per lane, and every
-// persistent launch had a ~1 ms floor (drain of the last reservations) however short its queue.
+// Queue consumption for the persistent kernels.  One returning atomic on a single word saturates at ~88 per
+// microsecond on MI355X (MI355X_MICROARCH.md, "dequeue"), so (1) a wavefront reserves a whole chunk of entries at a
+// time and hands them to its idle lanes from wave-uniform registers (ballot + mbcnt prefix), and (2) the queue has
+// WF_CURSORS cursor words that deal out INTERLEAVED chunks: reservation j of cursor k covers entries
+// [(j * WF_CURSORS + k) * chunk, + chunk), a wavefront starts on cursor (its number mod WF_CURSORS) and moves on to
+// the next one when its own is exhausted.  All wavefronts still work in one moving window of the queue (one region
+// of the scene: the cache locality a partition into eight contiguous parts lost, +17 % when tried), but the
+// reservations may be small without the cursor becoming the limit: with ONE word a tile shard's bounce-1 launch
+// (10 M rays, 64-entry reservations) ran at exactly 88 x 64 = 5.6 G rays/s, 2/3 of the full frame's rate.
+// The reservation shrinks with the queue (>= ~16 reservations per wavefront, 64 ... WF_CHUNK entries): a wavefront
+// holds at most one unfinished reservation when the queue runs dry, and that is what the drain phase costs.
 #ifndef WF_CHUNK
 #define WF_CHUNK 512u
 #endif
@@ -122,26 +133,41 @@ struct WaveFetch {
     uint32_t cur, end;
     bool done;
     uint32_t chunk;
+    uint32_t cursor;   // the cursor word this wavefront draws from
 };
 PT_D uint32_t wf_chunk_for(uint32_t n) {
     const uint32_t per_wave = n / (gridDim.x * (blockDim.x / 64u) * 16u);
     return per_wave >= WF_CHUNK ? WF_CHUNK : per_wave >= 256u ? 256u : per_wave >= 128u ? 128u : 64u;
 }
+PT_D WaveFetch wf_fetch_init(uint32_t n) {
+    const uint32_t wave = blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
+    return WaveFetch{0u, 0u, false, wf_chunk_for(n), wave & (WF_CURSORS - 1u)};
+}
 
-PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursor, uint32_t n, bool need, bool& got, bool& exhausted) {
+PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursors, uint32_t n, bool need, bool& got, bool& exhausted) {
     got = false;
     unsigned long long m = __ballot(need);
     if (!m) return 0;
-    if (wf.cur >= wf.end && !wf.done) {
+    while (wf.cur >= wf.end && !wf.done) {   // (wave-uniform: at most WF_CURSORS turns, normally one)
         int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if ((int)__lane_id() == leader) base = atomicAdd(cursor, wf.chunk);
-        base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
+        uint32_t j = 0;
+        if ((int)__lane_id() == leader) j = atomicAdd(&cursors[wf.cursor * WF_CURSOR_STRIDE], 1u);
+        j = __builtin_amdgcn_readfirstlane(__shfl(j, leader));
+        const unsigned long long base = ((unsigned long long)j * WF_CURSORS + wf.cursor) * wf.chunk;
         if (base >= n) {
-            wf.done = true;
+            // this cursor is exhausted: LOOK at the others (plain L2 reads - 5120 wavefronts probing eight words with
+            // returning atomics cost 0.4 ms per launch) and move to one that still has a reservation to give
+            uint32_t next = WF_CURSORS;
+            for (uint32_t t = 1; t < WF_CURSORS; ++t) {
+                const uint32_t k = (wf.cursor + t) & (WF_CURSORS - 1u);
+                const uint32_t seen = __hip_atomic_load(&cursors[k * WF_CURSOR_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (((unsigned long long)seen * WF_CURSORS + k) * wf.chunk < n && next == WF_CURSORS) next = k;
+            }
+            if (next == WF_CURSORS) wf.done = true;
+            else wf.cursor = next;
         } else {
-            wf.cur = base;
-            wf.end = base + wf.chunk < n ? base + wf.chunk : n;
+            wf.cur = (uint32_t)base;
+            wf.end = base + wf.chunk < n ? (uint32_t)base + wf.chunk : n;
         }
     }
     uint32_t w = 0;
@@ -507,8 +533,12 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
     __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
     wf_load_tree_top(S, lds_top);
+#ifdef WF_EXIT_TIMES
+    if (COUNT && threadIdx.x == 0 && W.bounce < 8) atomicMin(&gctr->launch_start[W.bounce], __builtin_amdgcn_s_memrealtime());
+    unsigned long long t_queue_done = 0;
+#endif
     const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
-    uint32_t* cursor = &ctr[W.bounce].trace_work;
+    uint32_t* cursor = ctr[W.bounce].trace_work;
     uint32_t ov_node[PT_KD_STACK - WF_LDS_STACK];
     float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
     const TravStack st = {(wf_lds_u64*)(lds_stack + threadIdx.x), ov_node, ov_tmax, (const wf_lds_u64*)lds_top};
@@ -521,7 +551,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
     uint32_t lstate = WF_LANE_IDLE;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     uint32_t cast_nodes0 = 0;
-    WaveFetch wf = {0u, 0u, false, wf_chunk_for(n)};
+    WaveFetch wf = wf_fetch_init(n);
 
     // the current cast has no further segment: best = next entry of the sorted hit list (or none)
     // (called from ONE place per loop iteration to keep the kernel's register footprint small)
@@ -634,6 +664,9 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
             }
         }
         WF_STAMP(st_refill);
+#ifdef WF_EXIT_TIMES
+        if (COUNT && wf.done && !t_queue_done) t_queue_done = __builtin_amdgcn_s_memrealtime();
+#endif
         if (!__any(active)) {
             if (__all(exhausted)) break;
             continue;
@@ -676,6 +709,15 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
         atomicAdd(&gctr->stamps[5], st_walk_steps);
         atomicAdd(&gctr->stamps[6], st_leaf_lanes);
         atomicAdd(&gctr->stamps[7], st_leaf_runs);
+    }
+#endif
+#ifdef WF_EXIT_TIMES
+    if (COUNT && (threadIdx.x & 63u) == 0 && W.bounce < 8) {
+        const uint32_t w = blockIdx.x * (WF_THREADS / 64u) + (threadIdx.x >> 6);
+        if (w < 8192u) {
+            gctr->wave_exit[W.bounce][w] = __builtin_amdgcn_s_memrealtime();
+            gctr->wave_queue_done[W.bounce][w] = t_queue_done;
+        }
     }
 #endif
     if (COUNT) {
@@ -741,6 +783,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
     LocalCtr lc = {0, 0, 0, 0, 0, 0};   // (GRID: casts made here)
     __shared__ uint32_t sh_cnt[2][WF_SHADE_THREADS / 64];
     __shared__ uint32_t sh_base[2];
+    __shared__ uint32_t sh_oct[8][WF_SHADE_THREADS / 64], sh_oct_off[8][WF_SHADE_THREADS / 64];
     const uint32_t wave = threadIdx.x >> 6;
     // grid-stride over the queue, one workgroup-wide step at a time (the loop bound is uniform in
     // the workgroup: every thread reaches the barriers of the compaction)
@@ -906,7 +949,22 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
     // ---- compaction: survivors -> queue[b+1], surface hits -> shadow queue.  One atomic per
     // workgroup and queue (wave ballots -> LDS -> one lane), not one per wavefront: the counter
     // word would otherwise cap the kernel at ~88 M wave-atomics per second.
+    // Coherence sorting (W.sort_octants): the survivors of a workgroup step - paths that started in the same few
+    // 8x8 pixel blocks - are placed in the workgroup's slice of the queue by the OCTANT of their new direction
+    // (ballot per octant, mbcnt rank, prefix over octants and waves in LDS), so that the 64 consecutive records a
+    // wavefront of the next k_wf_trace launch fetches walk the tree in the same child order.  The position of a
+    // record in a queue is free (results are keyed by out_slot), so no bit of the image changes.
     unsigned long long m_next = __ballot(survive), m_sh = __ballot(to_shadow);
+    uint32_t oct = 0, oct_rank = 0;
+    if (W.sort_octants) {
+        oct = (next_d.x < 0.f ? 1u : 0u) | (next_d.y < 0.f ? 2u : 0u) | (next_d.z < 0.f ? 4u : 0u);
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const unsigned long long m = __ballot(survive && oct == k);
+            if ((threadIdx.x & 63u) == 0) sh_oct[k][wave] = (uint32_t)__popcll(m);
+            if (oct == k) oct_rank = wf_lane_rank(m);
+        }
+    }
     if ((threadIdx.x & 63u) == 0) {
         sh_cnt[0][wave] = (uint32_t)__popcll(m_next);
         sh_cnt[1][wave] = (uint32_t)__popcll(m_sh);
@@ -917,6 +975,12 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
         for (uint32_t k = 0; k < WF_SHADE_THREADS / 64; ++k) total += sh_cnt[threadIdx.x][k];
         uint32_t* counter = threadIdx.x == 0 ? &ctr[bounce + 1].queue_count : &ctr[bounce].shadow_count;
         sh_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
+    } else if (W.sort_octants && threadIdx.x >= 64u && threadIdx.x < 64u + 8u * (WF_SHADE_THREADS / 64)) {
+        // exclusive prefix of the (octant, wave) counts, octant-major
+        const uint32_t e = threadIdx.x - 64u;
+        uint32_t before = 0;
+        for (uint32_t j = 0; j < e; ++j) before += sh_oct[j / (WF_SHADE_THREADS / 64)][j % (WF_SHADE_THREADS / 64)];
+        sh_oct_off[e / (WF_SHADE_THREADS / 64)][e % (WF_SHADE_THREADS / 64)] = before;
     }
     __syncthreads();
     uint32_t next_idx = sh_base[0] + wf_lane_rank(m_next), sh_idx = sh_base[1] + wf_lane_rank(m_sh);
@@ -924,6 +988,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
         next_idx += sh_cnt[0][k];
         sh_idx += sh_cnt[1][k];
     }
+    if (W.sort_octants) next_idx = sh_base[0] + sh_oct_off[oct][wave] + oct_rank;
     __syncthreads();  // sh_cnt / sh_base are rewritten by the next step
     if (GRID == 3 && survive) rng_planes_out[(size_t)W.cap + item] = later_words;   // draws 4-7 of the path
     if (survive) {
@@ -995,7 +1060,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
     __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
     wf_load_tree_top(S, lds_top);
     const uint32_t n = ctr[W.bounce].shadow_count;
-    uint32_t* cursor = &ctr[W.bounce].shadow_work;
+    uint32_t* cursor = ctr[W.bounce].shadow_work;
     uint32_t ov_node[PT_KD_STACK - WF_LDS_STACK];
     float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
     const TravStack st = {(wf_lds_u64*)(lds_stack + threadIdx.x), ov_node, ov_tmax, (const wf_lds_u64*)lds_top};
@@ -1014,7 +1079,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
     bool active = false, exhausted = false, need_begin = false;
     uint32_t lstate = WF_LANE_IDLE;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
-    WaveFetch wf = {0u, 0u, false, wf_chunk_for(n)};
+    WaveFetch wf = wf_fetch_init(n);
 
     auto add_light = [&]() {  // visibility known: add the light (mod.rs:251-261)
         if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) {
