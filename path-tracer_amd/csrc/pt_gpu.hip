@@ -983,7 +983,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             uint32_t total_items = blocks64 * 64u * nb;
             const pt_scene::WfPipe& pipe = s.pipe;
             hipStream_t st_main = stream;
-            hipStream_t st_shadow = wf_overlap ? pipe.side : st_main;
+            hipStream_t st_shadow = wf_overlap ? pipe.side : st_main;   // (not const: see the shadow stage)
             // opaque scenes, several chunks: the RNG planes of chunk c+1 are produced on their own stream while
             // chunk c runs its bounces (k_wf_rng is pure integer ALU work; the traversal kernels leave ~40 % of
             // the issue slots idle and end in a drain phase)
@@ -1133,6 +1133,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     }
                     HIP_CHECK(hipGetLastError());
                     stage_end();
+                    // (inline casts leave at most a few records in the shadow queue: that launch stays on the main stream,
+                    // behind a persistent trace grid on another stream it would wait milliseconds for a free slot)
+                    hipStream_t st_shadow_main = st_shadow;
+                    if (grid_mode != 0) st_shadow = st_main;
                     if (st_shadow != st_main) {
                         HIP_CHECK(hipEventRecord(pipe.ev_shade, st_main));
                         HIP_CHECK(hipStreamWaitEvent(st_shadow, pipe.ev_shade, 0));
@@ -1168,6 +1172,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     stage_end();
                     stage_stream = st_main;
                     if (st_shadow != st_main) HIP_CHECK(hipEventRecord(pipe.ev_shadow, st_shadow));
+                    else if (st_shadow_main != st_main) HIP_CHECK(hipEventRecord(pipe.ev_shadow, st_main));   // (keeps the waits below valid)
+                    st_shadow = st_shadow_main;
 #undef PT_OGS_ARGS
 #undef PT_LAUNCH_ACP
 #undef PT_LAUNCH_AC
