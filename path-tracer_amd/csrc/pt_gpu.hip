@@ -1009,6 +1009,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     return (uint32_t)(e && *e ? atoi(e) : 0);
                 }();
                 W.sort_octants = wf_sort;
+
                 W.refill_min = std::max(1u, std::min(64u, wf_refill));
                 W.walk_steps = std::max(1u, wf_walk);
                 WfCounters* wctr = (WfCounters*)pipe.ctr.p;

@@ -754,6 +754,9 @@ PT_D bool wf_light_is_moot(const DevLight& L, f3 term, f3 surface_pos) {
 #ifndef WF_SHADE_WAVES
 #define WF_SHADE_WAVES 4      // waves per SIMD the kernel is compiled for (register budget 512 / 4)
 #endif
+#ifndef WF_SHADE_AGGREGATE
+#define WF_SHADE_AGGREGATE 1  // bounces >= 1: retire the misses first, shade the hits 256 at a time (see the kernel)
+#endif
 #ifndef WF_SHADE_GRID_WAVES
 #define WF_SHADE_GRID_WAVES 4 // the same for the variants that cast through origin grids inline
 #endif
@@ -785,11 +788,9 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
     __shared__ uint32_t sh_base[2];
     __shared__ uint32_t sh_oct[8][WF_SHADE_THREADS / 64], sh_oct_off[8][WF_SHADE_THREADS / 64];
     const uint32_t wave = threadIdx.x >> 6;
-    // grid-stride over the queue, one workgroup-wide step at a time (the loop bound is uniform in
-    // the workgroup: every thread reaches the barriers of the compaction)
-    for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS) {
-    uint32_t i = base + threadIdx.x;
-    bool live = i < n;
+    // One workgroup-wide step: thread t shades queue entry i (live = it has one).  Every thread of the workgroup
+    // calls this together: the compaction at the end has barriers.
+    auto shade_one = [&](const uint32_t i, bool live) {
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), color = mk3(0, 0, 0);
     uint32_t item = i, draw = 0, out_slot = 0;
     RawHit h;
@@ -1023,7 +1024,63 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
         n_draws += GRID >= 2 ? draw
                              : draw - (ALPHA ? draws[i] : PRIMARY ? 0u : (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu)) +
                                    ((ALPHA && PRIMARY) ? 2u : 0u);
-    }  // grid-stride loop
+    };  // shade_one
+    if (PRIMARY || !WF_SHADE_AGGREGATE) {
+        // grid-stride over the queue, one workgroup-wide step at a time (the loop bound is uniform in the workgroup)
+        for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS)
+            shade_one(base + threadIdx.x, base + threadIdx.x < n);
+    } else {
+        // Hit aggregation (bounces >= 1).  Three of four secondary rays of an open scene leave into the background:
+        // shaded in queue order, 23 % of the lanes would carry the material fetch, the BRDF and the GGX sample while
+        // the others wait (27.7 of 64 lanes active per vector instruction, profiles/r02_a_pmc.json).  So a first
+        // pass over a step's 256 entries retires the misses (background term, mod.rs:184-186: 48 of the 64 record
+        // bytes) and collects the indices of the hits in LDS; whenever 256 are waiting - or the queue has ended -
+        // they are shaded together.  The order in which paths are shaded is free (results are keyed by out_slot),
+        // so no bit changes.
+        __shared__ uint32_t agg[2 * WF_SHADE_THREADS];
+        __shared__ uint32_t agg_cnt[WF_SHADE_THREADS / 64];
+        uint32_t have = 0;   // waiting hits (the same value in every thread)
+        uint32_t base = blockIdx.x * WF_SHADE_THREADS;
+        while (true) {
+            while (have < WF_SHADE_THREADS && base < n) {
+                const uint32_t i = base + threadIdx.x;
+                base += gridDim.x * WF_SHADE_THREADS;
+                bool is_hit = false;
+                if (i < n) {
+                    is_hit = hits[i].x != 0xffffffffu;
+                    if (!is_hit) {
+                        const float4* q = queue_in + (size_t)i * 4;
+                        const float4 q1 = q[1], q2 = q[2], q3 = q[3];
+                        const uint32_t slot = __float_as_uint(q3.z);
+                        if (slot != 0xffffffffu) {
+                            const f3 c = mk3(q2.y, q2.z, q2.w) + mul_ew(mk3(q1.z, q1.w, q2.x), ld3(S.background));
+                            float* out = staging + (size_t)slot * 3;
+                            out[0] = c.x;
+                            out[1] = c.y;
+                            out[2] = c.z;
+                        }
+                    }
+                }
+                const unsigned long long m = __ballot(is_hit);
+                if ((threadIdx.x & 63u) == 0) agg_cnt[wave] = (uint32_t)__popcll(m);
+                __syncthreads();
+                uint32_t pos = have + wf_lane_rank(m), total = 0;
+                for (uint32_t k = 0; k < WF_SHADE_THREADS / 64; ++k) {
+                    if (k < wave) pos += agg_cnt[k];
+                    total += agg_cnt[k];
+                }
+                if (is_hit) agg[pos] = i;
+                have += total;
+                __syncthreads();
+            }
+            if (have == 0) break;
+            const uint32_t take = have < WF_SHADE_THREADS ? have : (uint32_t)WF_SHADE_THREADS;
+            have -= take;
+            const uint32_t mine = threadIdx.x < take ? agg[have + threadIdx.x] : 0u;
+            __syncthreads();
+            shade_one(mine, threadIdx.x < take);
+        }
+    }
     if (COUNT && n_draws) atomicAdd(&gctr->rng_draws, (unsigned long long)n_draws);
     if (COUNT && n_new) atomicAdd(&gctr->samples, (unsigned long long)n_new);
     if (COUNT && n_moot) {
