@@ -380,17 +380,41 @@ PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float l
     return trav_pop(T, st, limit) ? WF_LANE_WALK : WF_LANE_DONE;  // empty leaf: straight on to the next segment
 }
 
+#ifndef WF_MAILBOX
+#define WF_MAILBOX 0   // one-entry mailbox in leaf_closest (measured: see DESIGN.md section 4)
+#endif
+#ifndef WF_LDS_LEAVES
+#define WF_LDS_LEAVES 0   // k_wf_trace: the leaf records of a wavefront's parked lanes staged through LDS (measured, ditto)
+#endif
+#define WF_LEAF_SLOTS 32u  // leaf records per wavefront and staging round (1536 B: five workgroups per CU still fit)
+
+// Inclusive prefix sum over the 64 lanes of a wavefront.
+PT_D uint32_t wf_scan_inclusive(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(v, d);
+        if ((int)__lane_id() >= d) v += up;
+    }
+    return v;
+}
 // (The 48-byte leaf records are read with plain loads: a primitive is referenced from ~7 leaves, and
 // marking these loads non-temporal cost 19 % of the trace stage.)
 // Closest-hit candidate update for one leaf (same acceptance rule as next_hit()).
 template <bool COUNT>
 PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_prev, uint32_t ord_prev, RawHit& best,
-                       LocalCtr& lc) {
+                       LocalCtr& lc, uint32_t& mailbox) {
     const float4* lp = S.leaf_prims + (size_t)leaf.x * 3;
     uint32_t n = leaf.y >> 2;
     for (uint32_t i = 0; i < n; ++i) {
-        float4 q0 = lp[3 * i], q1 = lp[3 * i + 1], q2 = lp[3 * i + 2];
+        float4 q0 = lp[3 * i];
         uint32_t pid = __float_as_uint(q0.w);
+#if WF_MAILBOX
+        // a primitive is referenced from ~7 leaves: the one tested last need not be tested again (the acceptance rule
+        // is idempotent: the same (distance, order) never replaces itself)
+        if (pid == mailbox) continue;
+        mailbox = pid;
+#endif
+        float4 q1 = lp[3 * i + 1], q2 = lp[3 * i + 2];
         if (COUNT) lc.tris++;
         if (!(pid & PT_PRIM_SPHERE)) {
             float dist, u, v;
@@ -532,6 +556,10 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
                                                          WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
     __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
+#if WF_LDS_LEAVES
+    __shared__ float4 lds_leaf_rec[WF_THREADS / 64][WF_LEAF_SLOTS * 3];
+    __shared__ uint32_t lds_leaf_addr[WF_THREADS / 64][WF_LEAF_SLOTS];
+#endif
     wf_load_tree_top(S, lds_top);
 #ifdef WF_EXIT_TIMES
     if (COUNT && threadIdx.x == 0 && W.bounce < 8) atomicMin(&gctr->launch_start[W.bounce], __builtin_amdgcn_s_memrealtime());
@@ -549,6 +577,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
     uint32_t ord_prev = 0, idx = 0, item = 0, draw = 0;
     bool active = false, exhausted = false;
     uint32_t lstate = WF_LANE_IDLE;
+    uint32_t mailbox = 0xffffffffu;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     uint32_t cast_nodes0 = 0;
     WaveFetch wf = wf_fetch_init(n);
@@ -578,6 +607,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
                 best.key = INFINITY;
                 best.ord = 0xffffffffu;
                 best.pid = 0xffffffffu;
+                mailbox = 0xffffffffu;
                 finished = !trav_start(S, T, T.o, T.d, next_start(t_prev, T.d));
                 if (COUNT) lc.restarts++;
                 if (finished) hit = false;
@@ -655,6 +685,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
                 t_prev = -INFINITY;
                 ord_prev = 0;
                 have_kept = false;
+                mailbox = 0xffffffffu;
                 best.key = INFINITY;
                 best.ord = 0xffffffffu;
                 best.pid = 0xffffffffu;
@@ -691,10 +722,50 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
             st_leaf_runs++;
         }
 #endif
+#if WF_LDS_LEAVES
+        // Triangle vertices through LDS: the parked lanes of the wavefront need sum(n) 48-byte leaf records at
+        // scattered places.  Instead of every lane loading its records one after the other (n dependent round trips
+        // to memory), the wavefront lists the record numbers in LDS, loads ALL their 16-byte thirds together - lane
+        // j takes third j, 64 at a time, whoever owns the record - into a staging area, and every parked lane tests
+        // its records from there.
+        {
+            const bool parked = lstate == WF_LANE_LEAF;
+            if (wf_any(parked)) {
+                const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+                const uint32_t n_rec = parked ? T.leaf.y >> 2 : 0u;
+                uint32_t tested = 0;
+                while (true) {   // (wave-uniform: one round unless more than WF_LEAF_SLOTS records are waiting)
+                    const uint32_t want = n_rec - tested;
+                    const uint32_t incl = wf_scan_inclusive(want), excl = incl - want;
+                    const uint32_t all = __builtin_amdgcn_readlane(incl, 63);
+                    if (all == 0u) break;
+                    const uint32_t total = all < WF_LEAF_SLOTS ? all : WF_LEAF_SLOTS;
+                    const uint32_t grant = excl >= WF_LEAF_SLOTS ? 0u : (want < WF_LEAF_SLOTS - excl ? want : WF_LEAF_SLOTS - excl);
+                    for (uint32_t k = 0; k < grant; ++k) lds_leaf_addr[wv][excl + k] = T.leaf.x + tested + k;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t j = lane; j < 3u * total; j += 64u) {
+                        const uint32_t r = j / 3u;
+                        lds_leaf_rec[wv][j] = S.leaf_prims[(size_t)lds_leaf_addr[wv][r] * 3 + (j - 3u * r)];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t k = 0; k < grant; ++k) {
+                        const float4* rec = &lds_leaf_rec[wv][(excl + k) * 3u];
+                        og_test_closest<COUNT>(T.o, T.d, rec[0], rec[1], rec[2], t_prev, ord_prev, best, lc);
+                    }
+                    tested += grant;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (parked) lstate = trav_pop(T, st, best.key) ? WF_LANE_WALK : WF_LANE_DONE;
+            }
+        }
+#else
         if (lstate == WF_LANE_LEAF) {
-            leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc);
+            leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc, mailbox);
             lstate = trav_pop(T, st, best.key) ? WF_LANE_WALK : WF_LANE_DONE;
         }
+#endif
         WF_STAMP(st_leaf);
         if (lstate == WF_LANE_DONE) complete();
         WF_STAMP(st_done);
@@ -1135,6 +1206,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
     best.pid = 0xffffffffu;
     bool active = false, exhausted = false, need_begin = false;
     uint32_t lstate = WF_LANE_IDLE;
+    uint32_t mailbox = 0xffffffffu;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     WaveFetch wf = wf_fetch_init(n);
 
@@ -1178,6 +1250,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
             blocked = false;
             t_prev = -INFINITY;
             ord_prev = 0;
+            mailbox = 0xffffffffu;
             best.key = INFINITY;
             best.ord = 0xffffffffu;
             best.pid = 0xffffffffu;
@@ -1232,6 +1305,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
             if (more) {
                 t_prev = best.key;
                 ord_prev = best.ord;
+                mailbox = 0xffffffffu;
                 best.key = INFINITY;
                 best.ord = 0xffffffffu;
                 best.pid = 0xffffffffu;
@@ -1317,7 +1391,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
                 }
                 lstate = (blocked || !trav_pop(T, st, limit)) ? WF_LANE_DONE : WF_LANE_WALK;
             } else {
-                leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc);
+                leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc, mailbox);
                 lstate = trav_pop(T, st, best.key) ? WF_LANE_WALK : WF_LANE_DONE;
             }
         }
