@@ -1,4 +1,4 @@
-"""Mutation fuzzing of the parsers that take untrusted bytes: ISF scene files, PNG textures, profile YAML.
+"""Mutation fuzzing of the parsers that take untrusted bytes: ISF scene files, PNG textures, profile YAML, glTF / GLB.
 Every input must come back as a status code (PT_OK or an error with a message), never as a crash.  Meant to run
 against the sanitized host library:  bash tools/asan_host.sh builds it; or standalone:
 
@@ -15,6 +15,17 @@ golden = pathlib.Path(__file__).resolve().parent.parent / "tests" / "golden"
 scenes = sorted(golden.glob("scenes/*/scene.isf")) or sorted(golden.rglob("*.isf"))
 pngs = sorted(golden.rglob("*.png"))
 assert scenes and pngs, (len(scenes), len(pngs))
+# glTF corpus: the small scene of tests/test_convert.py as .gltf (base64 buffer) and as .glb
+sys.path.insert(0, str(golden.parent))
+import base64, json, struct
+import test_convert
+_doc, _blob, _ = test_convert.build_gltf(embed_png=True)
+_doc["buffers"] = [{"byteLength": len(_blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(_blob).decode()}]
+GLTF = json.dumps(_doc).encode()
+_doc["buffers"] = [{"byteLength": len(_blob)}]
+_js = json.dumps(_doc).encode(); _js += b" " * (-len(_js) % 4); _bin = _blob + b"\x00" * (-len(_blob) % 4)
+GLB = (b"glTF" + struct.pack("<II", 2, 12 + 8 + len(_js) + 8 + len(_bin)) + struct.pack("<II", len(_js), 0x4E4F534A) + _js +
+       struct.pack("<II", len(_bin), 0x004E4942) + _bin)
 
 
 def mutate(data: bytes) -> bytes:
@@ -40,7 +51,7 @@ ok = err = 0
 tmp = pathlib.Path(tempfile.mkdtemp(prefix="ptfuzz"))
 try:
     for it in range(iters):
-        which = it % 3
+        which = it % 4
         if which == 0:     # ISF: mutated scene next to the original textures
             src = rng.choice(scenes)
             d = tmp / "scene"
@@ -55,6 +66,10 @@ try:
             w, hh, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
             rc = L.pth_png_decode(data, len(data), rng.choice([1, 3]), C.byref(w), C.byref(hh), C.byref(px))
             if rc == 0: L.pth_free(px)
+        elif which == 3:   # glTF / GLB -> converter
+            name = "in.gltf" if it % 8 < 4 else "in.glb"
+            (tmp / name).write_bytes(mutate(GLTF if name.endswith("gltf") else GLB))
+            rc = L.pth_convert_gltf(os.fsencode(str(tmp / name)), os.fsencode(str(tmp / "conv")))
         else:              # profile YAML
             text = mutate(b"resolution:\n  width: 64\n  height: 48\nsamples: 4\nbounces: 2\nbrdf: COOK_TORRANCE\ntonemap: FILMIC\n")
             prof = pta.Profile()
