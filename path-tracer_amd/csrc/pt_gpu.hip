@@ -19,6 +19,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -792,16 +793,43 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     TileMap tm = make_tile_map(p, o, o.shard_rank);
     if (tm.n_local == 0) return;
 
-    // tile offset table (cached per configuration: no host sync in steady state)
+    // tile tables (cached per configuration: no host sync in steady state): the packed offset of every local tile
+    // (sharded renders), then - PT_TILE_ORDER=morton - the order in which the wavefront integrator visits the local
+    // tiles: along a Z curve over the tile grid instead of row by row
+    static const bool morton = [] {
+        const char* e = getenv("PT_TILE_ORDER");
+        return e && !strcmp(e, "morton");
+    }();
     const uint32_t* d_tiles = nullptr;
-    if (o.shard_count > 1) {
+    uint32_t tile_order_base = 0;
+    if (o.shard_count > 1 || morton) {
         auto key = std::make_tuple(p.width, p.height, o.shard_rank, o.shard_count, o.tile_w, o.tile_h);
         if (key != s.tile_key || !s.tile_table.p) {
-            s.tile_table.ensure(tm.offsets.size() * 4);
-            HIP_CHECK(hipMemcpy(s.tile_table.p, tm.offsets.data(), tm.offsets.size() * 4, hipMemcpyHostToDevice));
+            std::vector<uint32_t> table(tm.offsets);
+            if (morton) {
+                auto spread = [](uint32_t v) {   // bits of v to the even positions
+                    uint64_t x = v;
+                    x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+                    x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+                    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+                    x = (x | (x << 2)) & 0x3333333333333333ull;
+                    x = (x | (x << 1)) & 0x5555555555555555ull;
+                    return x;
+                };
+                std::vector<std::pair<uint64_t, uint32_t>> order(tm.n_local_tiles);
+                for (uint32_t lt = 0; lt < tm.n_local_tiles; ++lt) {
+                    const uint32_t k = o.shard_rank + lt * o.shard_count;
+                    order[lt] = {spread(k % tm.tiles_x) | (spread(k / tm.tiles_x) << 1), lt};
+                }
+                std::sort(order.begin(), order.end());
+                for (auto& e : order) table.push_back(e.second);
+            }
+            s.tile_table.ensure(table.size() * 4);
+            HIP_CHECK(hipMemcpy(s.tile_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice));
             s.tile_key = key;
         }
         d_tiles = (const uint32_t*)s.tile_table.p;
+        if (morton) tile_order_base = (uint32_t)tm.offsets.size();
     }
     float* accum = (float*)d_accum;
     if (!accum) {
@@ -830,6 +858,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     P.tiles_x = tm.tiles_x;
     P.tiles_y = tm.tiles_y;
     P.n_local = (uint32_t)tm.n_local;
+    P.tile_order_base = tile_order_base;
     pt_fastdiv_make((o.tile_w >> 3) * (o.tile_h >> 3), P.div_tile_blocks);
     pt_fastdiv_make(o.tile_w >> 3, P.div_tile_cols);
     pt_fastdiv_make(tm.tiles_x, P.div_tiles_x);

@@ -43,6 +43,7 @@ __device__ __forceinline__ ItemRef decode_item(const RenderParams& P, const uint
     uint32_t b64 = pt_fastdiv(g, P.div_batch), s_rel = g - b64 * batch;
     uint32_t blocks_per_tile = (P.tile_w >> 3) * (P.tile_h >> 3);
     uint32_t lt = pt_fastdiv(b64, P.div_tile_blocks), sub = b64 - lt * blocks_per_tile;
+    if (P.tile_order_base) lt = tile_offsets[P.tile_order_base + lt];   // (visiting order of the tiles, e.g. a Z curve)
     uint32_t waves_x = P.tile_w >> 3;
     uint32_t sub_y = pt_fastdiv(sub, P.div_tile_cols), sub_x = sub - sub_y * waves_x;
     uint32_t tx = sub_x * 8u + (lane & 7u);
