@@ -1018,12 +1018,12 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             // opaque scenes, several chunks: the RNG planes of chunk c+1 are produced on their own stream while
             // chunk c runs its bounces (k_wf_rng is pure integer ALU work; the traversal kernels leave ~40 % of
             // the issue slots idle and end in a drain phase)
-            // opaque scenes with both kinds of grid: the bounce-0 kernel computes the ChaCha block itself (GRID 3)
+            // both kinds of grid: the bounce-0 kernel computes the ChaCha block itself (GRID 3)
             static const bool fuse_rng = [] {
                 const char* e = getenv("PT_OG_FUSE_RNG");
                 return e && *e ? atoi(e) != 0 : true;
             }();
-            const bool fused_rng = fuse_rng && use_cam_grid && use_light_grids && !alpha;
+            const bool fused_rng = fuse_rng && use_cam_grid && use_light_grids;
             const bool rng_ahead = !fused_rng && wf_overlap && total_items > cap && pipe.side_rng != nullptr;
             uint32_t chunk_no = 0;
             for (uint32_t base = 0; base < total_items; base += cap, ++chunk_no) {
@@ -1152,7 +1152,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     if (timing && grid_mode >= 2) fused_marks.push_back(ev);
                     stage_begin(2);
                     if (grid_mode == 3) {
-                        if (counting) PT_LAUNCH_SHADE(false, true, true, 3);
+                        if (alpha && counting) PT_LAUNCH_SHADE(true, true, true, 3);
+                        else if (alpha) PT_LAUNCH_SHADE(true, false, true, 3);
+                        else if (counting) PT_LAUNCH_SHADE(false, true, true, 3);
                         else PT_LAUNCH_SHADE(false, false, true, 3);
                     } else if (grid_mode == 2) {
                         if (alpha && counting) PT_LAUNCH_SHADE(true, true, true, 2);

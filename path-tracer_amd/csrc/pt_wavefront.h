@@ -838,9 +838,9 @@ PT_D bool wf_light_is_moot(const DevLight& L, f3 term, f3 surface_pos) {
 //     per shaded hit); only surfaces whose normal is too long for the grids' margin still take the queue;
 // 2 - (bounce 0) 1 + the camera ray is cast HERE through the camera grid: no hits[] round trip, and the 44 % of
 //     the samples that leave into the background never reach a second kernel;
-// 3 - (bounce 0, opaque scenes) 2 + the item's ChaCha12 block is computed HERE instead of by k_wf_rng: the ~800
-//     integer instructions per item run underneath the memory latency of the casts, and only the paths that
-//     go on write the words of bounces 1 and 2 (plane 1 of the RNG planes).
+// 3 - (bounce 0) 2 + the item's ChaCha12 block is computed HERE instead of by k_wf_rng: the ~800 integer
+//     instructions per item run underneath the memory latency of the casts, and only the paths that go on write
+//     the words of bounces 1 and 2 (plane 1 of the RNG planes; a path has made at least four draws by then).
 template <bool ALPHA, bool COUNT, bool PRIMARY, int GRID>
 __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_SHADE_WAVES) void k_wf_shade(DevScene S, WfParams W,
                                                   const uint32_t* __restrict__ tile_offsets,
@@ -852,7 +852,6 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     uint4* rng_planes_out = const_cast<uint4*>(rng_planes);   // GRID == 3 writes plane 1 (nobody reads it before bounce 1)
     static_assert(GRID < 2 || PRIMARY, "the camera grid serves bounce 0");
-    static_assert(GRID != 3 || !ALPHA, "translucent scenes stage their RNG words (the alpha walk draws)");
     const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
     uint32_t n_draws = 0, n_new = 0, n_moot = 0, n_hits = 0, n_cam_tris = 0;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};   // (GRID: casts made here)
@@ -869,8 +868,20 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
     bool hit = false;
     WfRng rng;
     rng.block = 0xffffffffu;
-    float r1_0 = 0.f, r2_0 = 0.f;                       // GRID == 3: draws 2 and 3 of the item
-    uint4 later_words = make_uint4(0u, 0u, 0u, 0u);     //            words 4-7 (bounces 1 and 2)
+    uint32_t word2 = 0, word3 = 0;                      // GRID == 3: words 2 and 3 of the item's ChaCha block
+    uint4 later_words = make_uint4(0u, 0u, 0u, 0u);     //            words 4-7 (bounces 1 and 2; the alpha walk of bounce 0)
+    // rng.gen::<f32>() number idx (>= 2) of the path at bounce 0, GRID == 3: from the block in registers; beyond
+    // word 7 (more than three alpha draws) the block is derived again by wf_rng_draw
+    auto draw_b0 = [&](uint32_t idx) -> float {
+        if (idx >= WF_RNG_STAGED) return wf_rng_draw(rng, W, tile_offsets, rng_planes, item, idx);
+        uint32_t word = word2;
+        word = idx == 3u ? word3 : word;
+        word = idx == 4u ? later_words.x : word;
+        word = idx == 5u ? later_words.y : word;
+        word = idx == 6u ? later_words.z : word;
+        word = idx == 7u ? later_words.w : word;
+        return wf_rng_float(word);
+    };
     if (PRIMARY && live) {  // entry i is work item i: the initial path state, built in place
         ItemRef it = decode_item(W.P, tile_offsets, W.item_base + i);
         if (!it.valid) {
@@ -886,8 +897,8 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
                     float sx, sy;
                     primary_screen(S, it.x, it.y, W.P.width, W.P.height, wf_rng_float(w[0]), wf_rng_float(w[1]), sx, sy);
                     primary_from_screen(S, sx, sy, o, d);
-                    r1_0 = wf_rng_float(w[2]);
-                    r2_0 = wf_rng_float(w[3]);
+                    word2 = w[2];
+                    word3 = w[3];
                     later_words = make_uint4(w[4], w[5], w[6], w[7]);
                 } else {
                     const uint2 sc = *(const uint2*)(rng_planes + i);  // jittered screen position (k_wf_rng)
@@ -906,7 +917,8 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
                         const float opacity = hit_opacity(S, o, d, h);
                         if (COUNT) lc.shaded++;
                         bool stop = opacity >= 1.f;
-                        if (!stop && opacity > 0.001f) stop = wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++) < opacity;
+                        if (!stop && opacity > 0.001f)
+                            stop = (GRID == 3 ? draw_b0(draw++) : wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++)) < opacity;
                         if (stop) break;
                         kept = h;   // skipped: remember it, look for the next entry of the list
                         have_kept = true;
@@ -994,9 +1006,12 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
         if (bounce < bounces) {
             next_o = surf.pos + surf.normal * 0.00001f;
             float r1, r2;
-            if (GRID == 3) {
-                r1 = r1_0;
-                r2 = r2_0;
+            if (GRID == 3 && ALPHA) {
+                r1 = draw_b0(draw++);
+                r2 = draw_b0(draw++);
+            } else if (GRID == 3) {
+                r1 = wf_rng_float(word2);
+                r2 = wf_rng_float(word3);
                 draw += 2u;
             } else if (PRIMARY && !ALPHA) {   // draws 2 and 3 of the item: staged next to the screen position (k_wf_rng)
                 const uint2 w23 = *(const uint2*)((const uint32_t*)(rng_planes + item) + 2);
