@@ -131,6 +131,13 @@ typedef struct pth_origin_grid {
     uint32_t* cell_off;      /* malloc'd, n_cells + 1 */
     pth_grid_ref* refs;      /* malloc'd */
     double build_seconds;
+    /* kind 1: orthographic grid for rays of ONE direction (pth_ortho_grid_build): res x res cells over the plane
+     * (axis_u, axis_v), cell (iu, iv) = floor(((p . axis_u) - u0) * cells_per_unit), ... of the ray's origin p;
+     * axis_w = the rays' direction (unit); a list entry's `mindist` is MINUS an upper bound of the primitive's depth
+     * along axis_w: a ray starting at depth z tests the entries with key <= -z (nothing else lies ahead of it). */
+    uint32_t kind;
+    float axis_u[3], axis_v[3], axis_w[3];
+    float u0, v0, cells_per_unit;
 } pth_origin_grid;
 
 /* res = 0 chooses the resolution from the primitive count (PT_OG_RES overrides).  ray_offset: 0 for rays that
@@ -139,6 +146,9 @@ typedef struct pth_origin_grid {
  * takes the direction as it is: a camera matrix with a scale gives directions longer than 1). */
 int pth_origin_grid_build(const pt_scene_desc* desc, const float origin[3], uint32_t res, float ray_offset,
                           float max_dir_len, pth_origin_grid* out);
+/* The same for rays that all have `direction` (not necessarily unit: the shadow rays of a directional light,
+ * src/renderer/mod.rs:283-299, which run along -light.direction with no distance limit). */
+int pth_ortho_grid_build(const pt_scene_desc* desc, const float direction[3], uint32_t res, pth_origin_grid* out);
 void pth_origin_grid_free(pth_origin_grid* g);
 
 const char* pth_last_error(void);

@@ -143,7 +143,9 @@ class OriginGridC(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("res", C.c_uint32), ("n_cells", C.c_uint64), ("n_refs", C.c_uint64),
                 ("n_global", C.c_uint32), ("enabled", C.c_uint32), ("max_cell_refs", C.c_uint32),
                 ("ray_offset", C.c_float), ("cell_off", C.POINTER(C.c_uint32)), ("refs", C.POINTER(GridRef)),
-                ("build_seconds", C.c_double)]
+                ("build_seconds", C.c_double), ("kind", C.c_uint32), ("axis_u", C.c_float * 3),
+                ("axis_v", C.c_float * 3), ("axis_w", C.c_float * 3), ("u0", C.c_float), ("v0", C.c_float),
+                ("cells_per_unit", C.c_float)]
 
 
 class OracleStats(C.Structure):
@@ -167,7 +169,7 @@ _gpu = None
 HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_scene_generate_ps5",
                 "pth_scene_save_isf", "pth_convert_gltf", "pth_profile_load", "pth_profile_parse", "pth_png_read",
                 "pth_png_decode", "pth_png_write_rgb8", "pth_free", "pth_prim_count", "pth_kd_build",
-                "pth_kd_free", "pth_origin_grid_build", "pth_origin_grid_free", "pth_last_error"]
+                "pth_kd_free", "pth_origin_grid_build", "pth_ortho_grid_build", "pth_origin_grid_free", "pth_last_error"]
 # Every symbol include/ptgpu.h declares.
 GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_prep_create", "pt_prep_destroy", "pt_scene_create_from_prep",
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_gather_tiles", "pt_render_gathered", "pt_local_pixel_count", "pt_local_pixel_map",
@@ -209,6 +211,7 @@ def host_lib():
         L.pth_kd_free.restype = None
         L.pth_origin_grid_build.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_float), C.c_uint32, C.c_float,
                                             C.c_float, C.POINTER(OriginGridC)]
+        L.pth_ortho_grid_build.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_float), C.c_uint32, C.POINTER(OriginGridC)]
         L.pth_origin_grid_free.argtypes = [C.POINTER(OriginGridC)]
         L.pth_origin_grid_free.restype = None
         L.pth_last_error.restype = C.c_char_p
@@ -324,11 +327,16 @@ class OriginGrid:
     """pth_origin_grid (host/origin_grid.cpp): cube map of primitive lists around one point, with the cell lookup
     restated in numpy f32 exactly as the device computes it (csrc/pt_grid.h og_cell)."""
 
-    def __init__(self, host_scene, origin, res=0, ray_offset=0.0, max_dir_len=1.001):
+    def __init__(self, host_scene, origin=None, res=0, ray_offset=0.0, max_dir_len=1.001, direction=None):
+        """origin: cube-map grid around a point; direction: orthographic grid for rays of that direction."""
         import numpy as np
         self.c = OriginGridC()
-        o = (C.c_float * 3)(*[float(v) for v in origin])
-        check_host(host_lib().pth_origin_grid_build(host_scene.desc, o, res, ray_offset, max_dir_len, C.byref(self.c)))
+        if direction is not None:
+            dvec = (C.c_float * 3)(*[float(v) for v in direction])
+            check_host(host_lib().pth_ortho_grid_build(host_scene.desc, dvec, res, C.byref(self.c)))
+        else:
+            o = (C.c_float * 3)(*[float(v) for v in origin])
+            check_host(host_lib().pth_origin_grid_build(host_scene.desc, o, res, ray_offset, max_dir_len, C.byref(self.c)))
         self.enabled = bool(self.c.enabled)
         self.res, self.n_global, self.n_refs = int(self.c.res), int(self.c.n_global), int(self.c.n_refs)
         if self.enabled:
@@ -338,9 +346,20 @@ class OriginGrid:
             self.ref_mindist = raw[1::2].view(np.float32)
 
     def cells(self, w):
-        """Cell index of every direction w [n, 3] (f32 arithmetic of the device)."""
+        """Cell index of every direction w [n, 3] - orthographic grids: of every ray ORIGIN w - in the f32 arithmetic
+        of the device (csrc/pt_grid.h og_cell / og_cell_ortho)."""
         import numpy as np
         w = np.ascontiguousarray(w, np.float32).reshape(-1, 3)
+        if self.c.kind == 1:
+            au, av = np.array(list(self.c.axis_u), np.float32), np.array(list(self.c.axis_v), np.float32)
+            dot = lambda a: ((w[:, 0] * a[0] + w[:, 1] * a[1]).astype(np.float32) + w[:, 2] * a[2]).astype(np.float32)
+            with np.errstate(all="ignore"):
+                fu = ((dot(au) - np.float32(self.c.u0)) * np.float32(self.c.cells_per_unit)).astype(np.float32)
+                fv = ((dot(av) - np.float32(self.c.v0)) * np.float32(self.c.cells_per_unit)).astype(np.float32)
+            top = np.float32(self.res - 1)
+            iu = np.nan_to_num(np.where(fu >= 0, np.minimum(np.floor(fu), top), 0)).astype(np.int64)
+            iv = np.nan_to_num(np.where(fv >= 0, np.minimum(np.floor(fv), top), 0)).astype(np.int64)
+            return iv * self.res + iu
         a = np.abs(w)
         axis = np.where((a[:, 0] >= a[:, 1]) & (a[:, 0] >= a[:, 2]), 0, np.where(a[:, 1] >= a[:, 2], 1, 2))
         idx = np.arange(len(w))
@@ -357,6 +376,13 @@ class OriginGrid:
         iv = np.nan_to_num(iv).astype(np.int64)
         face = 2 * axis + (wa < 0)
         return (face * self.res + iv) * self.res + iu
+
+    def depth(self, p):
+        """Orthographic grids: depth of the points p along the rays' direction, as the device computes it."""
+        import numpy as np
+        p = np.ascontiguousarray(p, np.float32).reshape(-1, 3)
+        a = np.array(list(self.c.axis_w), np.float32)
+        return ((p[:, 0] * a[0] + p[:, 1] * a[1]).astype(np.float32) + p[:, 2] * a[2]).astype(np.float32)
 
     def candidates(self, cell):
         """(primitive words, mindist) of one cell, the global block in front."""

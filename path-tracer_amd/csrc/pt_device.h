@@ -43,13 +43,17 @@ struct DevLight {
 //   refs      8 B / reference: (primitive id | sphere bit, bits(lower bound of the distance from the origin));
 //             the first n_global references are tested by every ray
 // res == 0: no grid (the casts use the KD-tree).
+// kind 1 (orthographic, rays of one direction: the shadow rays of a directional light): res x res cells over the
+// plane (axis_u, axis_v); a reference's second word is MINUS an upper bound of the primitive's depth along axis_w.
 struct DevGrid {
     const uint32_t* cell_off;
     const uint2* refs;
     uint32_t res;
     uint32_t n_global;
     float half_res;
-    uint32_t _pad;
+    uint32_t kind;
+    float axis_u[3], axis_v[3], axis_w[3];
+    float u0, v0, cells_per_unit;
 };
 
 struct DevScene {

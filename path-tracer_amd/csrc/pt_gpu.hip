@@ -704,17 +704,22 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
                 P.info.grid_refs += P.cam_grid->g.n_refs;
             }
         }
-        // lights: the shadow queue is consumed by ONE kernel, so the grids serve the shadow rays only when every
-        // light is a point light with a grid.  A shadow ray starts n * 1e-5 off the line through the light
-        // (mod.rs:291,319): the grids' margin covers |n| <= 1.5, longer normals take the KD-tree per surface.
+        // lights: the shadow queue is consumed by ONE kernel, so the grids serve the shadow rays only when EVERY
+        // light has one - a cube map around a point light, an orthographic grid along a directional light.  A
+        // point light's shadow ray starts n * 1e-5 off the line through the light (mod.rs:319): the grids' margin
+        // covers |n| <= 1.5, longer normals take the KD-tree per surface.
         bool all = grids_on && d.n_lights > 0 && n_prims > 0;
-        for (uint32_t i = 0; i < d.n_lights && all; ++i)
-            if (d.lights[i].kind != PT_LIGHT_POINT) all = false;
         const float max_normal = 1.5f;
         for (uint32_t i = 0; i < d.n_lights && all; ++i) {
             P.light_grids.push_back(std::make_unique<pt_prep::Grid>());
-            if (pth_origin_grid_build(&d, d.lights[i].vec, 0, 1.05e-5f * max_normal, 1.001f, &P.light_grids.back()->g) != PT_OK)
-                fail(PT_ERR_INVALID, "origin grid (light %u): %s", i, pth_last_error());
+            int rc;
+            if (d.lights[i].kind == PT_LIGHT_POINT) {
+                rc = pth_origin_grid_build(&d, d.lights[i].vec, 0, 1.05e-5f * max_normal, 1.001f, &P.light_grids.back()->g);
+            } else {   // the shadow rays run along -direction (mod.rs:291), as it is
+                const float sd[3] = {-1.f * d.lights[i].vec[0], -1.f * d.lights[i].vec[1], -1.f * d.lights[i].vec[2]};
+                rc = pth_ortho_grid_build(&d, sd, 0, &P.light_grids.back()->g);
+            }
+            if (rc != PT_OK) fail(PT_ERR_INVALID, "origin grid (light %u): %s", i, pth_last_error());
             if (!P.light_grids.back()->g.enabled) all = false;
         }
         if (!all) P.light_grids.clear();
@@ -763,6 +768,13 @@ void scene_upload(const pt_prep& P, int device, pt_scene& s) {
         out.res = g.res;
         out.n_global = g.n_global;
         out.half_res = 0.5f * (float)g.res;
+        out.kind = g.kind;
+        memcpy(out.axis_u, g.axis_u, 12);
+        memcpy(out.axis_v, g.axis_v, 12);
+        memcpy(out.axis_w, g.axis_w, 12);
+        out.u0 = g.u0;
+        out.v0 = g.v0;
+        out.cells_per_unit = g.cells_per_unit;
     };
     memset(&D.cam_grid, 0, sizeof D.cam_grid);
     if (P.cam_grid) upload_grid(P.cam_grid->g, D.cam_grid);

@@ -29,6 +29,15 @@ PT_D uint32_t og_cell(const DevGrid& G, f3 w) {
     return (face * G.res + (uint32_t)cv) * G.res + (uint32_t)cu;
 }
 
+// Orthographic grid: cell of the ray ORIGIN p (host mirror: OriginGrid.cells), and the scan limit -depth(p).
+PT_D uint32_t og_cell_ortho(const DevGrid& G, f3 p) {
+    const float fu = (dot3(p, ld3(G.axis_u)) - G.u0) * G.cells_per_unit, fv = (dot3(p, ld3(G.axis_v)) - G.v0) * G.cells_per_unit;
+    const float top = (float)(G.res - 1u);
+    const float cu = fu >= 0.f ? fminf(floorf(fu), top) : 0.f;
+    const float cv = fv >= 0.f ? fminf(floorf(fv), top) : 0.f;
+    return (uint32_t)cv * G.res + (uint32_t)cu;
+}
+
 // Candidate update with one primitive record (v0 | id, e1 | e2.x, e2.yz): the acceptance rule of next_hit().
 template <bool COUNT>
 PT_D void og_test_closest(f3 o, f3 d, float4 q0, float4 q1, float4 q2, float t_prev, uint32_t ord_prev, RawHit& best,
@@ -92,8 +101,10 @@ PT_D bool og_next_hit(const DevScene& S, const DevGrid& G, uint32_t cell, f3 o, 
     return best.pid != 0xffffffffu;
 }
 
-// Opaque scenes: is there any hit with |hit - pos| <= ldist (mod.rs:319-321 with every opacity exactly 1)?
-template <bool COUNT>
+// Opaque scenes: is there any hit - RANGED (point light): with |hit - pos| <= ldist (mod.rs:319-321 with every
+// opacity exactly 1); otherwise (directional light, mod.rs:291-297) any hit at all?  `ldist` is also the scan limit
+// of the list (point light: distance surface - light; directional: minus the depth of the ray's origin).
+template <bool COUNT, bool RANGED>
 PT_D bool og_blocked(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, f3 sd, f3 pos, float ldist, LocalCtr& lc) {
     const uint32_t first = G.cell_off[cell], last = G.cell_off[cell + 1u];
     const uint32_t n_all = G.n_global + (last - first);
@@ -109,7 +120,7 @@ PT_D bool og_blocked(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, 
             bool bf;
             if (!isect_triangle(so, sd, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), t, u, v, bf))
                 continue;
-            if (mag3((so + sd * t) - pos) > ldist) continue;
+            if (RANGED && mag3((so + sd * t) - pos) > ldist) continue;
             return true;
         } else {
             float t[2], key[2];
@@ -117,7 +128,7 @@ PT_D bool og_blocked(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, 
             const int nh = isect_sphere(so, sd, mk3(q0.x, q0.y, q0.z), q1.x, t, key, ex);
             for (int h = 0; h < nh; ++h) {
                 if (!(key[h] == key[h])) continue;
-                if (mag3((so + sd * t[h]) - pos) > ldist) continue;
+                if (RANGED && mag3((so + sd * t[h]) - pos) > ldist) continue;
                 return true;
             }
         }
@@ -126,21 +137,46 @@ PT_D bool og_blocked(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, 
 }
 
 
-// get_light_info (mod.rs:301-331) for point light `li` through its grid: the radiance that reaches the surface
-// (pos, normal gn, uv, kind).  The caller has checked that |gn| is within the grids' margin.
+// get_light_info (mod.rs:281-333) for light `li` through its grid: the radiance that reaches the surface (pos,
+// normal gn, uv, kind).  Point light: cube map around the light, looked up with (pos - light); the caller has checked
+// that |gn| is within the grid's margin.  Directional light: orthographic grid, looked up with the ray's origin.
 template <bool ALPHA, bool COUNT>
 PT_D f3 og_light_radiance(const DevScene& S, uint32_t li, f3 pos, f3 gn, f2 uv, bool sphere, LocalCtr& lc) {
     const DevLight& L = S.lights[li];
     const DevGrid& G = S.light_grids[li];
+    const f3 so = pos + gn * 0.00001f;   // NORMAL_BIAS (mod.rs:58)
+    if (COUNT) lc.shadow_rays++;
+    if (L.kind != PT_LIGHT_POINT) {   // mod.rs:283-299: every hit of the whole ray counts, sampled at ITS surface
+        const f3 sd = -1.f * ld3(L.vec);
+        f3 rad = ld3(L.color);
+        const uint32_t cell = og_cell_ortho(G, so);
+        const float limit = -dot3(so, ld3(G.axis_w));
+        if (!ALPHA) {
+            if (og_blocked<COUNT, false>(S, G, cell, so, sd, pos, limit, lc)) rad = rad * 0.0f;
+            return rad;
+        }
+        float t_prev = -INFINITY;
+        uint32_t ord_prev = 0;
+        RawHit h;
+        bool first = true;
+        while (og_next_hit<COUNT>(S, G, cell, so, sd, INFINITY, limit, t_prev, ord_prev, h, lc)) {
+            if (COUNT && !first) lc.restarts++;
+            first = false;
+            rad = rad * (1.f - hit_opacity(S, so, sd, h));
+            if (sum3(rad) == 0.f) break;
+            t_prev = h.key;
+            ord_prev = h.ord;
+        }
+        return rad;
+    }
     f3 direction = pos - ld3(L.vec);
     const uint32_t cell = og_cell(G, direction);
     const float ldist = mag3(direction);
     direction = normalize3(direction);
     f3 rad = ld3(L.color) / (4.f * PT_PI * ldist * ldist);
-    const f3 so = pos + gn * 0.00001f, sd = -1.f * direction;   // NORMAL_BIAS (mod.rs:58)
-    if (COUNT) lc.shadow_rays++;
+    const f3 sd = -1.f * direction;
     if (!ALPHA) {
-        if (og_blocked<COUNT>(S, G, cell, so, sd, pos, ldist, lc)) rad = rad * 0.0f;
+        if (og_blocked<COUNT, true>(S, G, cell, so, sd, pos, ldist, lc)) rad = rad * 0.0f;
         return rad;
     }
     // walk the sorted list, attenuating by (1 - opacity) (mod.rs:319-329)

@@ -26,6 +26,7 @@
 //     rounded down), so "stop at the first primitive farther than the best hit / the light" is safe.
 // A grid with too many global primitives is not built (enabled = 0) and the casts stay on the KD-tree.
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -93,6 +94,12 @@ struct GridParams {
     double ray_offset;    // world units by which a ray may miss O (0: camera)
     double max_dir_len;   // longest ray direction (Triangle::intersect does not normalise it)
     double abs_slack;     // world units subtracted from every stored distance
+    // orthographic grids (rays with ONE direction: the shadow rays of a directional light)
+    bool ortho = false;
+    Vec axis_u{1, 0, 0}, axis_v{0, 1, 0}, axis_w{0, 0, 1};   // axis_w = the rays' direction (unit); u, v span the grid plane
+    double u0 = 0, v0 = 0, cells_per_unit = 1;
+    double ray_len = 1;    // |direction| of the rays (Triangle::intersect takes it as it is)
+    double reach_max = 0;  // largest |ray origin - vertex| (the scene's diagonal: the rays start anywhere in the scene)
 };
 
 float round_down(double v) {
@@ -165,6 +172,79 @@ Footprint triangle_footprint(const GridParams& P, const float* v) {
     return fp;
 }
 
+// Orthographic grid: every ray has the direction ray_len * axis_w and starts anywhere in the scene.  The stored key
+// is MINUS an upper bound of the primitive's depth along axis_w (so that lists ascend like the origin grids' and
+// "key > -depth(ray origin)" ends the scan: such a primitive lies entirely behind the ray's start).
+Footprint triangle_footprint_ortho(const GridParams& P, const float* v) {
+    Footprint fp;
+    Vec a{v[0], v[1], v[2]}, b{v[8], v[9], v[10]}, c{v[16], v[17], v[18]};
+    Vec e1 = b - a, e2 = c - a, n = cross(e1, e2);
+    const double l1 = len(e1), l2 = len(e2), ln = len(n), lmax = std::max(l1, l2);
+    if (!std::isfinite(len(a)) || !std::isfinite(len(b)) || !std::isfinite(len(c)) || !std::isfinite(ln)) {
+        fp.global = true;
+        return fp;
+    }
+    // the same error model as triangle_footprint(); the determinant is the same for every ray: dl (n . axis_w) - and
+    // since the direction is known, so are the magnitudes of the products that are rounded on the way to it
+    // (p = d x e2: two products and a difference per component; det = e1 . p: three products, two sums).  An axis-
+    // aligned face seen exactly edge-on by an axis-aligned light gets the bound 0: its f32 determinant IS 0.
+    const double dl = P.ray_len;
+    const Vec dv = P.axis_w * dl;
+    const double pa[3] = {std::fabs(dv.y * e2.z) + std::fabs(dv.z * e2.y), std::fabs(dv.z * e2.x) + std::fabs(dv.x * e2.z),
+                          std::fabs(dv.x * e2.y) + std::fabs(dv.y * e2.x)};
+    const Vec pv = cross(dv, e2);
+    const double e_det = 2.0 * kEps32 * (2.0 * (std::fabs(e1.x) * pa[0] + std::fabs(e1.y) * pa[1] + std::fabs(e1.z) * pa[2]) +
+                                         3.0 * (std::fabs(e1.x * pv.x) + std::fabs(e1.y * pv.y) + std::fabs(e1.z * pv.z)));
+    const double e_num = 10.0 * kEps32 * dl * P.reach_max * lmax;
+    const double thr = 1e-6 * (1.0 - 1e-5) - e_det;
+    const double det = dl * std::fabs(dot(n, P.axis_w));
+    if (thr > 0 && det < thr) {   // (edge-on to the light: the f32 test rejects it for every ray)
+        fp.skip = true;
+        return fp;
+    }
+    const double det_lo = std::max(det - e_det, thr > 0 ? thr : 0.0);
+    const double slop = det_lo > 0 ? (e_num + e_det) / det_lo * (l1 + l2) : INFINITY;
+    const double margin = P.base_margin + slop * P.cells_per_unit;
+    if (!(margin <= P.max_margin)) {
+        fp.global = true;
+        return fp;
+    }
+    fp.n = 3;
+    fp.poly[0] = a;
+    fp.poly[1] = b;
+    fp.poly[2] = c;
+    fp.margin = margin;
+    const double depth = std::max(dot(a, P.axis_w), std::max(dot(b, P.axis_w), dot(c, P.axis_w))) + slop + P.abs_slack;
+    float key = (float)-depth;
+    if ((double)key > -depth) key = std::nextafterf(key, -INFINITY);   // round towards "deeper"
+    fp.mindist = key;
+    return fp;
+}
+
+Footprint sphere_footprint_ortho(const GridParams& P, const pt_model& mo) {
+    Footprint fp;
+    Vec c{mo.center[0], mo.center[1], mo.center[2]};
+    const double r = std::fabs((double)mo.radius);
+    if (!std::isfinite(len(c)) || !std::isfinite(r)) {
+        fp.global = true;
+        return fp;
+    }
+    // silhouette: a disc of radius r around the centre; the f32 discriminant of a grazing ray moves it by ~ eps * reach
+    const double slop = 64.0 * kEps32 * (P.reach_max + r);
+    const double rad = (r * 1.002 + slop) / std::cos(M_PI / 8);
+    fp.n = 8;
+    for (int k = 0; k < 8; ++k) {
+        const double ang = 2 * M_PI * k / 8;
+        fp.poly[k] = c + P.axis_u * (rad * std::cos(ang)) + P.axis_v * (rad * std::sin(ang));
+    }
+    fp.margin = P.base_margin;
+    const double depth = dot(c, P.axis_w) + r + slop + P.abs_slack;
+    float key = (float)-depth;
+    if ((double)key > -depth) key = std::nextafterf(key, -INFINITY);
+    fp.mindist = key;
+    return fp;
+}
+
 Footprint sphere_footprint(const GridParams& P, const pt_model& mo) {
     Footprint fp;
     Vec c{mo.center[0], mo.center[1], mo.center[2]};
@@ -221,10 +301,67 @@ int clip_plane(const Vec* in, int n, Vec k, Vec* out) {
     return m;
 }
 
+// Calls emit(base + iy * R + ix) for every cell whose margin-grown square the convex polygon (px, py) - in cell units -
+// may touch.  Edge functions of the polygon: a cell is dropped when its grown square lies entirely outside one edge;
+// slivers (no reliable orientation) and tiny boxes keep their whole bounding box.
+template <class Emit>
+void cover_cells(const double* px, const double* py, int n, bool all, double m, uint32_t R, size_t base, Emit&& emit) {
+    double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    for (int i = 0; i < n && !all; ++i) {
+        x0 = std::min(x0, px[i]);
+        x1 = std::max(x1, px[i]);
+        y0 = std::min(y0, py[i]);
+        y1 = std::max(y1, py[i]);
+    }
+    if (all) {
+        x0 = y0 = 0;
+        x1 = y1 = R;
+    }
+    auto cell_lo = [&](double v) { return (uint32_t)std::min<double>(R - 1, std::max(0.0, std::floor(v - m))); };
+    auto cell_hi = [&](double v) { return (uint32_t)std::min<double>(R - 1, std::max(0.0, std::floor(v + m))); };
+    uint32_t ix0 = cell_lo(x0), ix1 = cell_hi(x1), iy0 = cell_lo(y0), iy1 = cell_hi(y1);
+    double area2 = 0;
+    if (!all)
+        for (int i = 0; i < n; ++i) {
+            int j = (i + 1) % n;
+            area2 += px[i] * py[j] - px[j] * py[i];
+        }
+    const bool trim = !all && (ix1 - ix0 >= 2 || iy1 - iy0 >= 2) && std::fabs(area2) > 1e-6;
+    const double orient = area2 > 0 ? 1.0 : -1.0;
+    for (uint32_t iy = iy0; iy <= iy1; ++iy)
+        for (uint32_t ix = ix0; ix <= ix1; ++ix) {
+            if (trim) {
+                const double cx0 = ix - m, cx1 = ix + 1.0 + m, cy0 = iy - m, cy1 = iy + 1.0 + m;
+                bool outside = false;
+                for (int i = 0; i < n && !outside; ++i) {
+                    int j = (i + 1) % n;
+                    // inside(p) = orient * cross(edge, p - v_i) >= 0; take the corner that maximises it
+                    double ex = px[j] - px[i], ey = py[j] - py[i];
+                    double nx = -ey * orient, ny = ex * orient;   // inward normal
+                    double cx = nx >= 0 ? cx1 : cx0, cy = ny >= 0 ? cy1 : cy0;
+                    double val = nx * (cx - px[i]) + ny * (cy - py[i]);
+                    // (an absolute epsilon in cell^2 units keeps touching cells)
+                    if (val < -1e-9 * (std::fabs(nx) + std::fabs(ny)) * R) outside = true;
+                }
+                if (outside) continue;
+            }
+            emit(base + (size_t)iy * R + ix);
+        }
+}
+
 // Calls emit(cell) for every cell of every face whose (margin-grown) square the projection of the footprint may touch.
 template <class Emit>
 void rasterize(const GridParams& P, const Footprint& fp, Emit&& emit) {
     const uint32_t R = P.res;
+    if (P.ortho) {   // parallel projection onto the plane (axis_u, axis_v): one "face"
+        double px[kMaxPoly], py[kMaxPoly];
+        for (int i = 0; i < fp.n; ++i) {
+            px[i] = (dot(fp.poly[i], P.axis_u) - P.u0) * P.cells_per_unit;
+            py[i] = (dot(fp.poly[i], P.axis_v) - P.v0) * P.cells_per_unit;
+        }
+        cover_cells(px, py, fp.n, false, fp.margin, R, 0, emit);
+        return;
+    }
     const double half = 0.5 * R, m = fp.margin, mu = m * 2.0 / R;
     for (int face = 0; face < 6; ++face) {
         const int a = face >> 1, b = (a + 1) % 3, c = (a + 2) % 3;
@@ -242,7 +379,6 @@ void rasterize(const GridParams& P, const Footprint& fp, Emit&& emit) {
         }
         if (n == 0) continue;
         double px[kMaxPoly], py[kMaxPoly];
-        double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
         bool all = false;
         for (int i = 0; i < n; ++i) {
             double wa = s * comp(buf[cur][i], a);
@@ -252,48 +388,8 @@ void rasterize(const GridParams& P, const Footprint& fp, Emit&& emit) {
             }
             px[i] = (comp(buf[cur][i], b) / wa + 1.0) * half;
             py[i] = (comp(buf[cur][i], c) / wa + 1.0) * half;
-            x0 = std::min(x0, px[i]);
-            x1 = std::max(x1, px[i]);
-            y0 = std::min(y0, py[i]);
-            y1 = std::max(y1, py[i]);
         }
-        if (all) {
-            x0 = y0 = 0;
-            x1 = y1 = R;
-        }
-        auto cell_lo = [&](double v) { return (uint32_t)std::min<double>(R - 1, std::max(0.0, std::floor(v - m))); };
-        auto cell_hi = [&](double v) { return (uint32_t)std::min<double>(R - 1, std::max(0.0, std::floor(v + m))); };
-        uint32_t ix0 = cell_lo(x0), ix1 = cell_hi(x1), iy0 = cell_lo(y0), iy1 = cell_hi(y1);
-        // edge functions of the projected (convex) polygon: a cell is dropped when its grown square lies
-        // entirely outside one edge.  Slivers (no reliable orientation) and tiny boxes keep the whole box.
-        double area2 = 0;
-        if (!all)
-            for (int i = 0; i < n; ++i) {
-                int j = (i + 1) % n;
-                area2 += px[i] * py[j] - px[j] * py[i];
-            }
-        const bool trim = !all && (ix1 - ix0 >= 2 || iy1 - iy0 >= 2) && std::fabs(area2) > 1e-6;
-        const double orient = area2 > 0 ? 1.0 : -1.0;
-        const size_t face_base = (size_t)face * R * R;
-        for (uint32_t iy = iy0; iy <= iy1; ++iy)
-            for (uint32_t ix = ix0; ix <= ix1; ++ix) {
-                if (trim) {
-                    const double cx0 = ix - m, cx1 = ix + 1.0 + m, cy0 = iy - m, cy1 = iy + 1.0 + m;
-                    bool outside = false;
-                    for (int i = 0; i < n && !outside; ++i) {
-                        int j = (i + 1) % n;
-                        // inside(p) = orient * cross(edge, p - v_i) >= 0; take the corner that maximises it
-                        double ex = px[j] - px[i], ey = py[j] - py[i];
-                        double nx = -ey * orient, ny = ex * orient;   // inward normal
-                        double cx = nx >= 0 ? cx1 : cx0, cy = ny >= 0 ? cy1 : cy0;
-                        double val = nx * (cx - px[i]) + ny * (cy - py[i]);
-                        // (an absolute epsilon in cell^2 units keeps touching cells)
-                        if (val < -1e-9 * (std::fabs(nx) + std::fabs(ny)) * R) outside = true;
-                    }
-                    if (outside) continue;
-                }
-                emit(face_base + (size_t)iy * R + ix);
-            }
+        cover_cells(px, py, n, all, m, R, (size_t)face * R * R, emit);
     }
 }
 
@@ -324,11 +420,12 @@ struct Builder {
             uint64_t p = spans[si].prim0;
             if (mo.kind == PT_MODEL_MESH) {
                 for (uint32_t t = 0; t < mo.tri_count; ++t, ++p) {
-                    fps[p] = triangle_footprint(P, d.triangles + (size_t)(mo.tri_first + t) * 24);
+                    const float* tri = d.triangles + (size_t)(mo.tri_first + t) * 24;
+                    fps[p] = P.ortho ? triangle_footprint_ortho(P, tri) : triangle_footprint(P, tri);
                     prim_word[p] = (uint32_t)p;
                 }
             } else {
-                fps[p] = sphere_footprint(P, mo);
+                fps[p] = P.ortho ? sphere_footprint_ortho(P, mo) : sphere_footprint(P, mo);
                 prim_word[p] = (uint32_t)p | 0x80000000u;
             }
         });
@@ -362,53 +459,19 @@ uint32_t auto_resolution(uint64_t n_prims) {
         int v = atoi(e);
         if (v > 0) return (uint32_t)std::min(8192, std::max(8, v));
     }
-    // cells about half the edge of a typical triangle: ~4 sqrt(n) cells across the 90 degrees of a face
+    // cells about half the edge of a typical triangle: ~4 sqrt(n) cells across the 90 degrees of a face (4096 from
+    // 260 k primitives, 8192 from 1.05 M: the 4 M-triangle translucent 4K frame of config 5 renders 16 % faster with
+    // 8192 than with 4096, for 8 GB instead of 3.8 GB of device memory and 4.4 s instead of 1.6 s of build time)
     double want = 4.0 * std::sqrt((double)std::max<uint64_t>(1, n_prims));
     uint32_t r = 32;
-    while (r < want && r < 4096) r *= 2;
+    while (r < want && r < 8192) r *= 2;
     return r;
 }
 
-void build(const pt_scene_desc& d, const float origin[3], uint32_t res, float ray_offset, float max_dir_len,
-           pth_origin_grid& g) {
-    auto t0 = std::chrono::steady_clock::now();
-    memset(&g, 0, sizeof g);
-    memcpy(g.origin, origin, 12);
+// Footprints -> lists: count, scan, fill, sort.  Shared by the cube-map grids around a point and the orthographic
+// grids along a direction.
+void fill_lists(const pt_scene_desc& d, const GridParams& P, pth_origin_grid& g, std::chrono::steady_clock::time_point t0) {
     const uint64_t n_prims = pth_prim_count(&d);
-    if (res == 0) res = auto_resolution(n_prims);
-    if (res > 8192) fail(PT_ERR_INVALID, "origin grid: resolution %u too large", res);
-    g.res = res;
-    g.n_cells = 6ull * res * res;
-    g.ray_offset = ray_offset;
-    if (!std::isfinite(origin[0]) || !std::isfinite(origin[1]) || !std::isfinite(origin[2])) return;  // enabled = 0
-
-    // scene extent (for the absolute slack of the stored distances)
-    double ext = 0;
-    for (uint64_t t = 0; t < d.n_triangles; ++t)
-        for (int k = 0; k < 3; ++k)
-            for (int a = 0; a < 3; ++a) {
-                double v = std::fabs((double)d.triangles[t * 24 + k * 8 + a] - origin[a]);
-                if (std::isfinite(v)) ext = std::max(ext, v);
-            }
-    for (uint32_t m = 0; m < d.n_models; ++m)
-        if (d.models[m].kind == PT_MODEL_SPHERE)
-            for (int a = 0; a < 3; ++a) {
-                double v = std::fabs((double)d.models[m].center[a] - origin[a]) + std::fabs((double)d.models[m].radius);
-                if (std::isfinite(v)) ext = std::max(ext, v);
-            }
-    GridParams P;
-    P.origin = Vec{origin[0], origin[1], origin[2]};
-    P.res = res;
-    P.base_margin = 0.125;
-    P.max_margin = 128.0;
-    P.max_dir_len = max_dir_len;
-    if (const char* e = getenv("PT_OG_MAX_MARGIN")) P.max_margin = std::max(0.5, atof(e));
-    // (the f32 rounding of the normalised shadow-ray direction moves the far end of the ray by ~1e-7 of its length)
-    P.ray_offset = ray_offset > 0 ? ray_offset + 4e-7 * ext : 0.0;
-    P.abs_slack = 1e-6 * ext + 1e-30;
-    // a ray that misses O by ray_offset deviates by ray_offset / distance: at most 1/8 cell beyond near_radius
-    P.near_radius = std::max(1e-5 * ext, P.ray_offset > 0 ? 3.0 * P.ray_offset / (0.125 * 2.0 / res) : 0.0);
-
     Builder B(d, P);
     B.footprints();
     std::vector<uint32_t> global;
@@ -485,6 +548,123 @@ void build(const pt_scene_desc& d, const float origin[3], uint32_t res, float ra
     g.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+void build(const pt_scene_desc& d, const float origin[3], uint32_t res, float ray_offset, float max_dir_len,
+           pth_origin_grid& g) {
+    auto t0 = std::chrono::steady_clock::now();
+    memset(&g, 0, sizeof g);
+    memcpy(g.origin, origin, 12);
+    const uint64_t n_prims = pth_prim_count(&d);
+    if (res == 0) res = auto_resolution(n_prims);
+    if (res > 8192) fail(PT_ERR_INVALID, "origin grid: resolution %u too large", res);
+    g.res = res;
+    g.n_cells = 6ull * res * res;
+    g.ray_offset = ray_offset;
+    if (!std::isfinite(origin[0]) || !std::isfinite(origin[1]) || !std::isfinite(origin[2])) return;  // enabled = 0
+
+    // scene extent (for the absolute slack of the stored distances)
+    double ext = 0;
+    for (uint64_t t = 0; t < d.n_triangles; ++t)
+        for (int k = 0; k < 3; ++k)
+            for (int a = 0; a < 3; ++a) {
+                double v = std::fabs((double)d.triangles[t * 24 + k * 8 + a] - origin[a]);
+                if (std::isfinite(v)) ext = std::max(ext, v);
+            }
+    for (uint32_t m = 0; m < d.n_models; ++m)
+        if (d.models[m].kind == PT_MODEL_SPHERE)
+            for (int a = 0; a < 3; ++a) {
+                double v = std::fabs((double)d.models[m].center[a] - origin[a]) + std::fabs((double)d.models[m].radius);
+                if (std::isfinite(v)) ext = std::max(ext, v);
+            }
+    GridParams P;
+    P.origin = Vec{origin[0], origin[1], origin[2]};
+    P.res = res;
+    P.base_margin = 0.125;
+    P.max_margin = 128.0;
+    P.max_dir_len = max_dir_len;
+    if (const char* e = getenv("PT_OG_MAX_MARGIN")) P.max_margin = std::max(0.5, atof(e));
+    // (the f32 rounding of the normalised shadow-ray direction moves the far end of the ray by ~1e-7 of its length)
+    P.ray_offset = ray_offset > 0 ? ray_offset + 4e-7 * ext : 0.0;
+    P.abs_slack = 1e-6 * ext + 1e-30;
+    // a ray that misses O by ray_offset deviates by ray_offset / distance: at most 1/8 cell beyond near_radius
+    P.near_radius = std::max(1e-5 * ext, P.ray_offset > 0 ? 3.0 * P.ray_offset / (0.125 * 2.0 / res) : 0.0);
+
+    fill_lists(d, P, g, t0);
+}
+
+void build_ortho(const pt_scene_desc& d, const float direction[3], uint32_t res, pth_origin_grid& g) {
+    auto t0 = std::chrono::steady_clock::now();
+    memset(&g, 0, sizeof g);
+    g.kind = 1;
+    const uint64_t n_prims = pth_prim_count(&d);
+    if (res == 0) res = auto_resolution(n_prims);
+    if (res > 8192) fail(PT_ERR_INVALID, "origin grid: resolution %u too large", res);
+    g.res = res;
+    g.n_cells = (uint64_t)res * res;
+    Vec w{direction[0], direction[1], direction[2]};
+    const double wl = len(w);
+    if (!std::isfinite(wl) || !(wl > 0) || wl > 1e6) return;   // enabled = 0
+    GridParams P;
+    P.ortho = true;
+    P.ray_len = wl * (1.0 + 1e-6);
+    P.axis_w = w * (1.0 / wl);
+    const Vec t = std::fabs(P.axis_w.x) < 0.6 ? Vec{1, 0, 0} : Vec{0, 1, 0};
+    P.axis_u = cross(P.axis_w, t);
+    P.axis_u = P.axis_u * (1.0 / len(P.axis_u));
+    P.axis_v = cross(P.axis_w, P.axis_u);
+    // the device computes the cell with the f32 images of the axes: use exactly those here
+    auto f32v = [](Vec v) { return Vec{(double)(float)v.x, (double)(float)v.y, (double)(float)v.z}; };
+    P.axis_u = f32v(P.axis_u);
+    P.axis_v = f32v(P.axis_v);
+    P.axis_w = f32v(P.axis_w);
+    // bounds of the scene in (u, v) and its diameter
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto grow = [&](Vec p, double r) {
+        if (!std::isfinite(len(p)) || !std::isfinite(r)) return;
+        const double c[3] = {dot(p, P.axis_u), dot(p, P.axis_v), dot(p, P.axis_w)};
+        const double q[3] = {p.x, p.y, p.z};
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], c[k] - r);
+            hi[k] = std::max(hi[k], c[k] + r);
+            bmin[k] = std::min(bmin[k], q[k] - r);
+            bmax[k] = std::max(bmax[k], q[k] + r);
+        }
+    };
+    for (uint64_t tr = 0; tr < d.n_triangles; ++tr)
+        for (int k = 0; k < 3; ++k) grow(Vec{d.triangles[tr * 24 + k * 8], d.triangles[tr * 24 + k * 8 + 1], d.triangles[tr * 24 + k * 8 + 2]}, 0.0);
+    for (uint32_t m = 0; m < d.n_models; ++m)
+        if (d.models[m].kind == PT_MODEL_SPHERE)
+            grow(Vec{d.models[m].center[0], d.models[m].center[1], d.models[m].center[2]}, std::fabs((double)d.models[m].radius));
+    if (!(hi[0] >= lo[0])) return;   // nothing finite in the scene: enabled = 0
+    const double diag = std::sqrt((bmax[0] - bmin[0]) * (bmax[0] - bmin[0]) + (bmax[1] - bmin[1]) * (bmax[1] - bmin[1]) +
+                                  (bmax[2] - bmin[2]) * (bmax[2] - bmin[2]));
+    const double span = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), 1e-6 * (diag + 1e-30));
+    P.res = res;
+    P.cells_per_unit = (res - 2.0) / span;   // one cell of border on every side
+    P.u0 = lo[0] - 1.0 / P.cells_per_unit;
+    P.v0 = lo[1] - 1.0 / P.cells_per_unit;
+    P.base_margin = 0.125 + 8.0 * kEps32 * (std::fabs(lo[0]) + std::fabs(hi[0]) + std::fabs(lo[1]) + std::fabs(hi[1])) * P.cells_per_unit;
+    P.max_margin = 128.0;
+    if (const char* e = getenv("PT_OG_MAX_MARGIN")) P.max_margin = std::max(0.5, atof(e));
+    P.max_dir_len = P.ray_len;
+    P.ray_offset = 0.0;
+    P.reach_max = diag * 1.01 + 1e-4;   // rays start on surfaces of the scene (+ normal * 1e-5)
+    P.abs_slack = 1e-5 * diag + 1e-30;  // (covers the f32 rounding of the ray origin's depth on the device)
+    P.near_radius = 0.0;
+    P.origin = Vec{0, 0, 0};
+    memcpy(g.axis_u, std::array<float, 3>{(float)P.axis_u.x, (float)P.axis_u.y, (float)P.axis_u.z}.data(), 12);
+    memcpy(g.axis_v, std::array<float, 3>{(float)P.axis_v.x, (float)P.axis_v.y, (float)P.axis_v.z}.data(), 12);
+    memcpy(g.axis_w, std::array<float, 3>{(float)P.axis_w.x, (float)P.axis_w.y, (float)P.axis_w.z}.data(), 12);
+    g.u0 = (float)P.u0;
+    g.v0 = (float)P.v0;
+    g.cells_per_unit = (float)P.cells_per_unit;
+    // (u0, v0, cells_per_unit as the device will use them)
+    P.u0 = g.u0;
+    P.v0 = g.v0;
+    P.cells_per_unit = g.cells_per_unit;
+    fill_lists(d, P, g, t0);
+}
+
 }  // namespace
 }  // namespace pth
 
@@ -497,6 +677,13 @@ int pth_origin_grid_build(const pt_scene_desc* desc, const float origin[3], uint
         if (!(ray_offset >= 0.f)) pth::fail(PT_ERR_INVALID, "pth_origin_grid_build: ray_offset must be >= 0");
         if (!(max_dir_len > 0.f && max_dir_len < 1e6f)) pth::fail(PT_ERR_INVALID, "pth_origin_grid_build: bad max_dir_len");
         pth::build(*desc, origin, res, ray_offset, max_dir_len, *out);
+    });
+}
+
+int pth_ortho_grid_build(const pt_scene_desc* desc, const float direction[3], uint32_t res, pth_origin_grid* out) {
+    return pth::guarded([&] {
+        if (!desc || !direction || !out) pth::fail(PT_ERR_INVALID, "pth_ortho_grid_build: null argument");
+        pth::build_ortho(*desc, direction, res, *out);
     });
 }
 

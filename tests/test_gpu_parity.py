@@ -331,9 +331,8 @@ def test_grid_kd_and_megakernel_paths_agree(pta, scene_cache, gpu_scene_cache, n
     g = gpu_scene_cache(name)
     info = g.info().as_dict()
     assert info["cam_grid_res"] > 0          # every reference scene gets a camera grid
-    point_only = all(scene_cache(name).desc.contents.lights[i].kind == pta.PT_LIGHT_POINT
-                     for i in range(scene_cache(name).n_lights))
-    assert (info["light_grids"] > 0) == (point_only and scene_cache(name).n_lights > 0)
+    # ... and every light a grid: a cube map around a point light, an orthographic grid along a directional one
+    assert info["light_grids"] == scene_cache(name).n_lights
     prof = pta.Profile.make(200, 150, 6, 5)
     rgb, acc = g.render(prof)
     rgb_kd, acc_kd = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_NO_GRIDS))

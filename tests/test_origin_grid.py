@@ -101,6 +101,50 @@ def test_light_grid_is_conservative(pta, oracle, scene_cache, name):
     assert n_checked > 100
 
 
+@pytest.mark.parametrize("name", ["head", "alpha_transparency", "white_furnace_direct", "spheres"])
+def test_directional_grid_is_conservative(pta, oracle, scene_cache, name):
+    """Shadow rays of a directional light (mod.rs:283-299): origin = hit + n * 1e-5, direction = -light.direction as it
+    is (not normalised), no distance limit.  The orthographic grid is looked up with the ray's ORIGIN; every primitive
+    of the brute-force hit list must be a candidate whose key (minus its depth bound) does not exceed minus the
+    depth of the origin."""
+    scene = scene_cache(name)
+    osc = oracle.OracleScene(scene.desc, oracle.PTO_BRUTE_FORCE)
+    prof = pta.Profile.make(256, 256, 4, 2)
+    rays = primary_rays(osc, prof, 1500, seed=21)
+    first, cnt = osc.trace_all(rays, 1)
+    ok = cnt > 0
+    lights = scene.desc.contents.lights
+    dirs = [np.array(list(lights[i].vec), np.float32) for i in range(scene.n_lights) if lights[i].kind == pta.PT_LIGHT_DIRECTIONAL]
+    dirs += [np.array(v, np.float32) for v in ([0.3, -2.0, 0.4], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0])]   # (+ arbitrary ones)
+    rng = np.random.default_rng(22)
+    n_checked = 0
+    for ldir in dirs:
+        sd = (-ldir).astype(np.float32)
+        grid = pta.OriginGrid(scene, direction=sd)
+        assert grid.enabled and grid.c.kind == 1
+        sphere = (first["flags"][ok, 0] & 2) != 0
+        dn = np.linalg.norm(rays[ok, 3:], axis=1).astype(np.float32)
+        tpar = np.where(sphere, first["dist"][ok, 0] / dn, first["dist"][ok, 0]).astype(np.float32)
+        pos = (rays[ok, :3] + rays[ok, 3:] * tpar[:, None]).astype(np.float32)
+        gn = rng.normal(size=pos.shape).astype(np.float32)
+        so = (pos + gn * np.float32(0.00001)).astype(np.float32)
+        srays = np.concatenate([so, np.broadcast_to(sd, so.shape)], axis=1).astype(np.float32)
+        hits, counts = osc.trace_all(srays, 16)
+        cells = grid.cells(so)
+        cut = -grid.depth(so)
+        for i in range(len(srays)):
+            if counts[i] == 0:
+                continue
+            prims, key = grid.candidates(int(cells[i]))
+            ids = prims & 0x7fffffff
+            for k in range(min(int(counts[i]), hits.shape[1])):
+                sel = np.nonzero(ids == int(hits[i, k]["prim"]))[0]
+                assert len(sel) > 0, (name, ldir, i, int(hits[i, k]["prim"]))
+                assert sel[0] < grid.n_global or key[sel[0]] <= cut[i], (name, i, float(key[sel[0]]), float(cut[i]))
+                n_checked += 1
+    assert n_checked > 50
+
+
 def test_generated_scene_grids(pta, oracle):
     scene = pta.HostScene.generate_ps5(20000, seed=0)
     osc = oracle.OracleScene(scene.desc, oracle.PTO_BVH)
