@@ -708,7 +708,7 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
         // light has one - a cube map around a point light, an orthographic grid along a directional light.  A
         // point light's shadow ray starts n * 1e-5 off the line through the light (mod.rs:319): the grids' margin
         // covers |n| <= 1.5, longer normals take the KD-tree per surface.
-        bool all = grids_on && d.n_lights > 0 && n_prims > 0;
+        bool all = grids_on && n_prims > 0;   // (no lights at all: vacuously)
         const float max_normal = 1.5f;
         for (uint32_t i = 0; i < d.n_lights && all; ++i) {
             P.light_grids.push_back(std::make_unique<pt_prep::Grid>());
