@@ -154,8 +154,11 @@ enum {
 };
 
 /* Which pixels this call renders.  The image is cut into tile_w x tile_h
- * tiles numbered row-major; this call renders tiles k with
- * k % shard_count == shard_rank.  Every pixel keeps its GLOBAL
+ * tiles numbered row-major (k = ty * tiles_x + tx); this call renders the tiles
+ * with (tx + ty * s) % shard_count == shard_rank - diagonal
+ * stripes, s = the smallest odd number >= 3 coprime to shard_count (1 for two
+ * ranks: a checkerboard), so that every rank takes tiles from every column and
+ * row of the image (pt_local_pixel_map gives the exact map).  Every pixel keeps its GLOBAL
  * index i = x + y*W in the seed formula (renderer/mod.rs:110-112), so any
  * sharding is bit-identical to the unsharded render.  Output buffers are
  * PACKED in local order: tiles in ascending k, row-major inside a tile

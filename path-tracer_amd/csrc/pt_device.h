@@ -95,6 +95,7 @@ struct RenderParams {
     uint32_t shard_rank, shard_count, tile_w, tile_h;
     uint32_t tiles_x, tiles_y;
     uint32_t n_local;       // pixels rendered by this call
+    uint32_t tile_k_base;      // != 0: tile_table[tile_k_base + lt] = global number of local tile lt (sharded renders)
     uint32_t tile_order_base;  // != 0: tile_table[tile_order_base + j] = the j-th local tile the wavefront integrator visits
     // exact division of the work-item decoding by multiply-high (pt_fastdiv, dividends < 2^27):
     // the sample batch, the 8x8 blocks of a tile, the 8-pixel columns of a tile, the tile columns of the image

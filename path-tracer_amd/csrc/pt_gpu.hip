@@ -83,7 +83,7 @@ int guarded(F&& fn) {
 // ------------------------------------------------------------------ pixel mapping
 // Thread -> pixel.  Grid: one 256-thread workgroup per quarter of a tile_w x
 // tile_h tile (4 wavefronts, each an 8x8 pixel block).  Local tile lt is global
-// tile k = shard_rank + lt * shard_count.
+// tile k = tile_table[tile_k_base + lt] (the rank's tiles in ascending order; unsharded: k = lt).
 struct PixelRef {
     uint32_t x, y;
     uint32_t global_index;  // x + y*W  (seed formula, mod.rs:107-112)
@@ -101,7 +101,7 @@ __device__ __forceinline__ PixelRef map_pixel(const RenderParams& P, const uint3
     uint32_t waves_x = P.tile_w >> 3;
     uint32_t tx = (wave % waves_x) * 8u + (lane & 7u);
     uint32_t ty = (wave / waves_x) * 8u + (lane >> 3);
-    uint32_t k = P.shard_rank + lt * P.shard_count;
+    uint32_t k = P.tile_k_base ? tile_offsets[P.tile_k_base + lt] : lt;
     uint32_t tile_x = k % P.tiles_x, tile_y = k / P.tiles_x;
     r.x = tile_x * P.tile_w + tx;
     r.y = tile_y * P.tile_h + ty;
@@ -182,10 +182,11 @@ __global__ __launch_bounds__(256) void k_postprocess(const float* __restrict__ a
     rgb8[3 * (size_t)i + 2] = as_u8(pt_pow_inv_gamma(c.z) * 255.f);
 }
 
-// gathered: shard_count slices of slice_pixels packed pixels; rank_tile_offsets[r * max_local + lt]
+// gathered: shard_count slices of slice_pixels packed pixels; tile_src[k] = rank (high 8 bits) and packed offset of
+// global tile k inside its rank's slice... as two words: tile_src[2k] = rank, tile_src[2k + 1] = offset
 __global__ __launch_bounds__(256) void k_assemble(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ image,
-                                                  const uint32_t* __restrict__ rank_tile_offsets, uint32_t max_local,
-                                                  uint32_t width, uint32_t height, uint32_t shard_count,
+                                                  const uint32_t* __restrict__ tile_src,
+                                                  uint32_t width, uint32_t height,
                                                   uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x,
                                                   uint64_t slice_pixels, uint32_t elem_bytes) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -193,9 +194,8 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t* __restrict__ ga
     uint32_t x = i % width, y = i / width;
     uint32_t tile_x = x / tile_w, tile_y = y / tile_h;
     uint32_t k = tile_y * tiles_x + tile_x;
-    uint32_t r = k % shard_count, lt = k / shard_count;
     uint32_t cw = min(tile_w, width - tile_x * tile_w);
-    uint64_t src = (uint64_t)r * slice_pixels + rank_tile_offsets[(size_t)r * max_local + lt] +
+    uint64_t src = (uint64_t)tile_src[2 * (size_t)k] * slice_pixels + tile_src[2 * (size_t)k + 1] +
                    (uint64_t)(y - tile_y * tile_h) * cw + (x - tile_x * tile_w);
     const uint8_t* s = gathered + src * elem_bytes;
     uint8_t* d = image + (uint64_t)i * elem_bytes;
@@ -370,6 +370,7 @@ struct TileMap {
     uint32_t n_local_tiles;
     uint64_t n_local;
     std::vector<uint32_t> offsets;  // n_local_tiles + 1 (only used when count > 1)
+    std::vector<uint32_t> tiles;    // global number (ty * tiles_x + tx) of every local tile, ascending
 };
 
 void normalise_opts(const pt_profile& p, const pt_opts* in, pt_opts& o) {
@@ -385,6 +386,27 @@ void normalise_opts(const pt_profile& p, const pt_opts* in, pt_opts& o) {
     if ((uint64_t)p.width * p.height >= (1ull << 31)) fail(PT_ERR_UNSUPPORTED, "image too large");
 }
 
+// Which rank renders tile (tx, ty): (tx + ty * stride) mod count - diagonal stripes, so that every rank takes tiles
+// from every column and every row of the image.  (k mod count, the obvious rule, degenerates into vertical stripes
+// whenever the tile columns are a multiple of count / 2: at 1920x1080 with 32x32 tiles and 8 ranks it gave each rank
+// every fourth column, and the per-rank frame times of config 3 ranged from 6.7 to 8.1 ms.)  stride = the smallest
+// odd number >= 3 that is coprime to count (1 for count <= 2: a checkerboard).
+uint32_t tile_rank_stride(uint32_t count) {
+    if (count <= 2) return 1;
+    for (uint32_t s = 3;; s += 2) {
+        uint32_t a = s, b = count;
+        while (b) {
+            uint32_t t = a % b;
+            a = b;
+            b = t;
+        }
+        if (a == 1) return s;
+    }
+}
+inline uint32_t tile_rank(uint32_t tx, uint32_t ty, uint32_t count, uint32_t stride) {
+    return (uint32_t)(((uint64_t)tx + (uint64_t)ty * stride) % count);
+}
+
 TileMap make_tile_map(const pt_profile& p, const pt_opts& o, uint32_t rank) {
     TileMap m;
     m.tile_w = o.tile_w;
@@ -393,19 +415,19 @@ TileMap make_tile_map(const pt_profile& p, const pt_opts& o, uint32_t rank) {
     m.tiles_y = (p.height + o.tile_h - 1) / o.tile_h;
     m.count = o.shard_count;
     m.rank = rank;
-    uint32_t n_tiles = m.tiles_x * m.tiles_y;
-    m.n_local_tiles = n_tiles > rank ? (n_tiles - rank + m.count - 1) / m.count : 0;
-    m.offsets.resize(m.n_local_tiles + 1);
+    const uint32_t stride = tile_rank_stride(m.count);
     uint64_t off = 0;
-    for (uint32_t lt = 0; lt < m.n_local_tiles; ++lt) {
-        uint32_t k = rank + lt * m.count;
-        uint32_t tx = k % m.tiles_x, ty = k / m.tiles_x;
-        uint32_t cw = std::min(o.tile_w, p.width - tx * o.tile_w);
-        uint32_t ch = std::min(o.tile_h, p.height - ty * o.tile_h);
-        m.offsets[lt] = (uint32_t)off;
-        off += (uint64_t)cw * ch;
-    }
-    m.offsets[m.n_local_tiles] = (uint32_t)off;
+    for (uint32_t ty = 0; ty < m.tiles_y; ++ty)
+        for (uint32_t tx = 0; tx < m.tiles_x; ++tx) {
+            if (m.count > 1 && tile_rank(tx, ty, m.count, stride) != rank) continue;
+            uint32_t cw = std::min(o.tile_w, p.width - tx * o.tile_w);
+            uint32_t ch = std::min(o.tile_h, p.height - ty * o.tile_h);
+            m.tiles.push_back(ty * m.tiles_x + tx);
+            m.offsets.push_back((uint32_t)off);
+            off += (uint64_t)cw * ch;
+        }
+    m.n_local_tiles = (uint32_t)m.tiles.size();
+    m.offsets.push_back((uint32_t)off);
     m.n_local = off;
     return m;
 }
@@ -813,11 +835,12 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         return e && !strcmp(e, "morton");
     }();
     const uint32_t* d_tiles = nullptr;
-    uint32_t tile_order_base = 0;
+    uint32_t tile_order_base = 0, tile_k_base = 0;
     if (o.shard_count > 1 || morton) {
         auto key = std::make_tuple(p.width, p.height, o.shard_rank, o.shard_count, o.tile_w, o.tile_h);
         if (key != s.tile_key || !s.tile_table.p) {
             std::vector<uint32_t> table(tm.offsets);
+            table.insert(table.end(), tm.tiles.begin(), tm.tiles.end());   // global tile numbers (tile_k_base)
             if (morton) {
                 auto spread = [](uint32_t v) {   // bits of v to the even positions
                     uint64_t x = v;
@@ -830,7 +853,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 };
                 std::vector<std::pair<uint64_t, uint32_t>> order(tm.n_local_tiles);
                 for (uint32_t lt = 0; lt < tm.n_local_tiles; ++lt) {
-                    const uint32_t k = o.shard_rank + lt * o.shard_count;
+                    const uint32_t k = tm.tiles[lt];
                     order[lt] = {spread(k % tm.tiles_x) | (spread(k / tm.tiles_x) << 1), lt};
                 }
                 std::sort(order.begin(), order.end());
@@ -841,7 +864,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             s.tile_key = key;
         }
         d_tiles = (const uint32_t*)s.tile_table.p;
-        if (morton) tile_order_base = (uint32_t)tm.offsets.size();
+        tile_k_base = (uint32_t)tm.offsets.size();
+        if (morton) tile_order_base = (uint32_t)(tm.offsets.size() + tm.tiles.size());
     }
     float* accum = (float*)d_accum;
     if (!accum) {
@@ -871,6 +895,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     P.tiles_y = tm.tiles_y;
     P.n_local = (uint32_t)tm.n_local;
     P.tile_order_base = tile_order_base;
+    P.tile_k_base = tile_k_base;
     pt_fastdiv_make((o.tile_w >> 3) * (o.tile_h >> 3), P.div_tile_blocks);
     pt_fastdiv_make(o.tile_w >> 3, P.div_tile_cols);
     pt_fastdiv_make(tm.tiles_x, P.div_tiles_x);
@@ -1399,7 +1424,7 @@ int pt_local_pixel_map(const pt_profile* profile, const pt_opts* opts, uint32_t*
         }
         TileMap tm = make_tile_map(p, o, o.shard_rank);
         for (uint32_t lt = 0; lt < tm.n_local_tiles; ++lt) {
-            uint32_t k = o.shard_rank + lt * o.shard_count;
+            uint32_t k = tm.tiles[lt];
             uint32_t tx = k % tm.tiles_x, ty = k / tm.tiles_x;
             uint32_t cw = std::min(o.tile_w, p.width - tx * o.tile_w), ch = std::min(o.tile_h, p.height - ty * o.tile_h);
             for (uint32_t y = 0; y < ch; ++y)
@@ -1484,16 +1509,17 @@ int pt_assemble_tiles(const pt_profile* profile, uint32_t shard_count, uint32_t 
             auto key = std::make_tuple(profile->width, profile->height, on.shard_count, on.tile_w, on.tile_h, dev);
             auto it = cache.find(key);
             if (it == cache.end()) {
-                std::vector<TileMap> maps;
+                std::vector<uint32_t> table;
                 for (uint32_t r = 0; r < on.shard_count; ++r) {
-                    maps.push_back(make_tile_map(*profile, on, r));
-                    c.max_local = std::max(c.max_local, maps.back().n_local_tiles);
+                    TileMap tm = make_tile_map(*profile, on, r);
+                    c.tiles_x = tm.tiles_x;
+                    c.max_local = std::max(c.max_local, tm.n_local_tiles);
+                    table.resize(2 * (size_t)tm.tiles_x * tm.tiles_y, 0u);
+                    for (uint32_t lt = 0; lt < tm.n_local_tiles; ++lt) {
+                        table[2 * (size_t)tm.tiles[lt]] = r;
+                        table[2 * (size_t)tm.tiles[lt] + 1] = tm.offsets[lt];
+                    }
                 }
-                c.tiles_x = maps[0].tiles_x;
-                std::vector<uint32_t> table((size_t)on.shard_count * std::max(1u, c.max_local), 0);
-                for (uint32_t r = 0; r < on.shard_count; ++r)
-                    for (uint32_t lt = 0; lt < maps[r].n_local_tiles; ++lt)
-                        table[(size_t)r * c.max_local + lt] = maps[r].offsets[lt];
                 HIP_CHECK(hipMalloc((void**)&c.d, table.size() * 4));
                 HIP_CHECK(hipMemcpy(c.d, table.data(), table.size() * 4, hipMemcpyHostToDevice));
                 it = cache.emplace(key, c).first;
@@ -1504,8 +1530,8 @@ int pt_assemble_tiles(const pt_profile* profile, uint32_t shard_count, uint32_t 
             if (make_tile_map(*profile, on, r).n_local > slice_pixels) fail(PT_ERR_INVALID, "slice_pixels too small for rank %u", r);
         uint32_t npix = profile->width * profile->height;
         hipLaunchKernelGGL(k_assemble, dim3((npix + 255u) / 256u), dim3(256), 0, (hipStream_t)hip_stream,
-                           (const uint8_t*)d_gathered, (uint8_t*)d_image, c.d, c.max_local, profile->width,
-                           profile->height, on.shard_count, on.tile_w, on.tile_h, c.tiles_x, slice_pixels, elem_bytes);
+                           (const uint8_t*)d_gathered, (uint8_t*)d_image, c.d, profile->width,
+                           profile->height, on.tile_w, on.tile_h, c.tiles_x, slice_pixels, elem_bytes);
         HIP_CHECK(hipGetLastError());
     });
 }

@@ -48,7 +48,7 @@ __device__ __forceinline__ ItemRef decode_item(const RenderParams& P, const uint
     uint32_t sub_y = pt_fastdiv(sub, P.div_tile_cols), sub_x = sub - sub_y * waves_x;
     uint32_t tx = sub_x * 8u + (lane & 7u);
     uint32_t ty = sub_y * 8u + (lane >> 3);
-    uint32_t k = P.shard_rank + lt * P.shard_count;
+    uint32_t k = P.tile_k_base ? tile_offsets[P.tile_k_base + lt] : lt;   // (the rank's tiles, ascending; unsharded: all)
     uint32_t tile_y = pt_fastdiv(k, P.div_tiles_x), tile_x = k - tile_y * P.tiles_x;
     r.x = tile_x * P.tile_w + tx;
     r.y = tile_y * P.tile_h + ty;

@@ -67,10 +67,13 @@ def test_pixel_maps_partition_the_image(pta):
             idx = pta.local_pixel_map(prof, opts)
             sizes.append(len(idx))
             seen[idx] += 1
-            # packed order: tiles ascending, row-major inside a tile
+            # packed order: tiles ascending, row-major inside a tile; tile (tx, ty) belongs to rank (tx + ty * s) % count
+            # (diagonal stripes: s = smallest odd number >= 3 coprime to count, 1 for count <= 2)
             tiles_x = (w + tile - 1) // tile
-            k = (idx // w // tile) * tiles_x + (idx % w) // tile
-            assert (np.diff(k) >= 0).all() and (k % count == r).all()
+            tx, ty = (idx % w) // tile, idx // w // tile
+            k = ty * tiles_x + tx
+            s = 1 if count <= 2 else next(v for v in range(3, 99, 2) if np.gcd(v, count) == 1)
+            assert (np.diff(k.astype(np.int64)) >= 0).all() and ((tx + ty * s) % count == r).all()
         assert (seen == 1).all()
         assert max(sizes) - min(sizes) <= 2 * tile * tile
     prof = pta.Profile.make(40, 30, 1, 1)

@@ -1,4 +1,4 @@
-"""Per-rank frame time of an N-way tile-sharded render, emulated on one GPU (rank 0's shard only):
+"""Per-rank frame time of an N-way tile-sharded render, emulated on one GPU (EVERY rank's shard, one after the other):
     python tools/shard_times.py [--spp 128] [--tris 500000]
 Prints ms per frame for shard_count = 1, 2, 4, 8 and the strong-scaling efficiency those imply
 (all-gather not included)."""
@@ -19,7 +19,7 @@ prof = pta.Profile.make(1920, 1080, a.spp, 5, "FILMIC")
 base = None
 for n in (1, 2, 4, 8):
     worst = 0.0
-    for r in sorted({0, n - 1}):
+    for r in range(n):
         opts = pta.Opts.make(flags=pta.PT_FLAG_TIMING, shard_rank=r, shard_count=n, tile_w=32, tile_h=32)
         npx = len(pta.local_pixel_map(prof, opts))
         rgb = torch.empty(npx * 3, dtype=torch.uint8, device='cuda')
@@ -34,5 +34,5 @@ for n in (1, 2, 4, 8):
         worst = max(worst, ms)
         t = g.timing().as_dict()
     base = base or worst
-    print(f"shards {n}: {worst:8.3f} ms per frame (slowest of first/last rank)  efficiency {base / (n * worst):.3f}  "
+    print(f"shards {n}: {worst:8.3f} ms per frame (slowest rank)  efficiency {base / (n * worst):.3f}  "
           f"stages {{'rng': {t['generate_ms']:.2f}, 'trace': {t['trace_ms']:.2f}, 'shade': {t['shade_ms']:.2f}, 'shadow': {t['shadow_ms']:.2f}}} launches {t['stage_launches']}")
