@@ -213,14 +213,33 @@ def main():
             kernels["k_wf_shade<GRID> (bounce 0: ChaCha12 block + camera cast + shading + shadow casts)"] = dict(
                 ms_per_frame=stage_ms["bounce0_ms"] / args.steps, launches_per_frame=per_frame,
                 bytes_per_frame=b0_bytes, units_per_launch=n_items // max(1, per_frame), unit="path samples")
-        trace_segments = counters["segments"] - (n_items if launches["bounce0_launches"] else 0)
-        trace_bytes = trace_segments * 80 + counters["trace_nodes"] * 8 + \
-            (counters["trace_tris"] - (counters["bounce0_tris"] if launches["bounce0_launches"] else 0)) * 36
-        trace_bytes = max(trace_bytes, trace_segments * 80)
+        fused = bool(launches["bounce0_launches"])
+        trace_segments = counters["segments"] - (n_items if fused else 0)
+        # closest-hit primitive tests of the KD casts (trace_tris also holds the camera casts of the fused kernel)
+        trace_tris = counters["trace_tris"] - (counters["bounce0_cam_tris"] if fused else 0)
+        trace_bytes = trace_segments * 80 + counters["trace_nodes"] * 8 + trace_tris * 36
         kernels["k_wf_trace (closest-hit KD-tree casts)"] = dict(
             ms_per_frame=stage_ms["integrate_ms"] / args.steps, launches_per_frame=trace_launches // args.steps,
             bytes_per_frame=trace_bytes, units_per_launch=trace_segments // max(1, trace_launches // args.steps),
             unit="ray casts")
+        # the shadow casts outside the fused kernel (k_og_shadow through the light grids, k_wf_shadow on the KD-tree):
+        # 104 B per ray cast + its node visits and primitive tests
+        sh_rays = counters["shadow_rays"] - counters["shadow_skipped"] - (counters["bounce0_shadow_rays"] if fused else 0)
+        sh_tris = counters["tris_tested"] - counters["trace_tris"] - \
+            ((counters["bounce0_tris"] - counters["bounce0_cam_tris"]) if fused else 0)
+        sh_nodes = counters["nodes_visited"] - counters["trace_nodes"]
+        # (one shadow stage per bounce iteration, i.e. per closest-hit launch or fused bounce-0 launch)
+        sh_launches = max(1, (launches["launches"] + launches["bounce0_launches"]) // args.steps)
+        if sh_rays > 0 and stage_ms["shadow_ms"] > 0:
+            sh_name = "k_og_shadow (shadow casts through the light grids)" if info["light_grids"] and \
+                not (args.opt_flags & pta.PT_FLAG_NO_GRIDS) else "k_wf_shadow (any-hit KD-tree casts)"
+            kernels[sh_name] = dict(
+                ms_per_frame=stage_ms["shadow_ms"] / args.steps, launches_per_frame=sh_launches,
+                bytes_per_frame=sh_rays * 104 + sh_nodes * 8 + sh_tris * 36,
+                units_per_launch=sh_rays // sh_launches, unit="shadow rays",
+                # HIP events on the side stream: the launches share the chip with k_wf_trace of the next bounce, so this
+                # is elapsed time beside another kernel, not the kernel alone (rocprofv3: profiles/*_kernel_stats.csv)
+                note="elapsed on the side stream, overlapped with k_wf_trace")
         name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms_per_frame"])
         avg_ms = dom["ms_per_frame"] / max(1, dom["launches_per_frame"])
         bytes_per_launch = dom["bytes_per_frame"] / max(1, dom["launches_per_frame"])
@@ -255,8 +274,10 @@ def main():
                     "units_per_launch": dom["units_per_launch"], "unit_name": dom["unit"],
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
                     "algorithmic_bytes_per_unit": round(bytes_per_launch / max(1, dom["units_per_launch"]), 1),
-                    "kernels": {k: {"ms_per_step": round(v["ms_per_frame"], 3), "launches_per_step": v["launches_per_frame"],
-                                    "algorithmic_GBps": round(v["bytes_per_frame"] / max(1e-9, v["ms_per_frame"] * 1e-3) / 1e9, 1)}
+                    "kernels": {k: dict({"ms_per_step": round(v["ms_per_frame"], 3), "launches_per_step": v["launches_per_frame"],
+                                         "algorithmic_GBps": round(v["bytes_per_frame"] / max(1e-9, v["ms_per_frame"] * 1e-3) / 1e9, 1),
+                                         "frac": round(v["bytes_per_frame"] / max(1e-9, v["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                                        **({"note": v["note"]} if "note" in v else {}))
                                 for k, v in kernels.items()},
                     "pipeline": {"algorithmic_bytes_per_sample": round(ceil_b, 1),
                                  "queue_floor_bytes_per_sample": round(floor_b, 1),

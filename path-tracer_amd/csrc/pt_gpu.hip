@@ -466,6 +466,7 @@ struct pt_scene {
     DevScene dev{};
     std::vector<void*> allocations;
     pt_scene_info info{};
+    bool ortho_light_grids = false;   // some light grid is orthographic (a directional light): kernel variants DIRL
     mutable pt_timing timing{};
     mutable pt_counters counters{};
     mutable DeviceBuffer accum_scratch, tile_table, counter_buf, staging_buf;
@@ -802,7 +803,10 @@ void scene_upload(const pt_prep& P, int device, pt_scene& s) {
     if (P.cam_grid) upload_grid(P.cam_grid->g, D.cam_grid);
     std::vector<DevGrid> lgrids(P.lights.size());
     for (auto& g : lgrids) memset(&g, 0, sizeof g);
-    for (size_t i = 0; i < P.light_grids.size(); ++i) upload_grid(P.light_grids[i]->g, lgrids[i]);
+    for (size_t i = 0; i < P.light_grids.size(); ++i) {
+        upload_grid(P.light_grids[i]->g, lgrids[i]);
+        if (P.light_grids[i]->g.kind != 0) s.ortho_light_grids = true;
+    }
     D.light_grids = s.upload(lgrids.data(), lgrids.size());
     s.info.upload_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_up).count();
 }
@@ -1164,6 +1168,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         else if (counting) PT_LAUNCH_SHADE(false, true, false, G);             \
         else PT_LAUNCH_SHADE(false, false, false, G);                          \
     } while (0)
+#define PT_LAUNCH_SHADE_P(G)                                            \
+    do {                                                                \
+        if (alpha && counting) PT_LAUNCH_SHADE(true, true, true, G);    \
+        else if (alpha) PT_LAUNCH_SHADE(true, false, true, G);          \
+        else if (counting) PT_LAUNCH_SHADE(false, true, true, G);       \
+        else PT_LAUNCH_SHADE(false, false, true, G);                    \
+    } while (0)
                     if (grid_mode < 2) {   // (grid_mode >= 2: k_wf_shade casts the camera rays itself)
                         stage_begin(1);
                         if (prim && use_cam_grid) {   // camera rays: one grid lookup instead of a KD walk (pt_grid_kernels.h)
@@ -1188,18 +1199,17 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     if (st_shadow != st_main && b > 0) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
                     if (timing && grid_mode >= 2) fused_marks.push_back(ev);
                     stage_begin(2);
+                    // (+4: the variants with the orthographic branch for directional lights compiled in)
+                    const bool dirl = s.ortho_light_grids;
                     if (grid_mode == 3) {
-                        if (alpha && counting) PT_LAUNCH_SHADE(true, true, true, 3);
-                        else if (alpha) PT_LAUNCH_SHADE(true, false, true, 3);
-                        else if (counting) PT_LAUNCH_SHADE(false, true, true, 3);
-                        else PT_LAUNCH_SHADE(false, false, true, 3);
+                        if (dirl) PT_LAUNCH_SHADE_P(7);
+                        else PT_LAUNCH_SHADE_P(3);
                     } else if (grid_mode == 2) {
-                        if (alpha && counting) PT_LAUNCH_SHADE(true, true, true, 2);
-                        else if (alpha) PT_LAUNCH_SHADE(true, false, true, 2);
-                        else if (counting) PT_LAUNCH_SHADE(false, true, true, 2);
-                        else PT_LAUNCH_SHADE(false, false, true, 2);
+                        if (dirl) PT_LAUNCH_SHADE_P(6);
+                        else PT_LAUNCH_SHADE_P(2);
                     } else if (grid_mode == 1) {
-                        PT_LAUNCH_SHADE_G(1);
+                        if (dirl) PT_LAUNCH_SHADE_G(5);
+                        else PT_LAUNCH_SHADE_G(1);
                     } else {
                         PT_LAUNCH_SHADE_G(0);
                     }
@@ -1229,10 +1239,16 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                         HIP_CHECK(hipGetLastError());
                     } else if (use_light_grids) {   // every light a point light with a grid: plain grid-stride kernel
                         const dim3 g((uint32_t)s.n_cu * 16u);
-                        if (alpha && counting) hipLaunchKernelGGL((k_og_shadow<true, true>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);
-                        else if (alpha) hipLaunchKernelGGL((k_og_shadow<true, false>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);
-                        else if (counting) hipLaunchKernelGGL((k_og_shadow<false, true>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);
-                        else hipLaunchKernelGGL((k_og_shadow<false, false>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);
+#define PT_LAUNCH_OGSH(A, C)                                                                                   \
+    do {                                                                                                       \
+        if (s.ortho_light_grids) hipLaunchKernelGGL((k_og_shadow<A, C, true>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS); \
+        else hipLaunchKernelGGL((k_og_shadow<A, C, false>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);          \
+    } while (0)
+                        if (alpha && counting) PT_LAUNCH_OGSH(true, true);
+                        else if (alpha) PT_LAUNCH_OGSH(true, false);
+                        else if (counting) PT_LAUNCH_OGSH(false, true);
+                        else PT_LAUNCH_OGSH(false, false);
+#undef PT_LAUNCH_OGSH
                         HIP_CHECK(hipGetLastError());
                         if (counting) hipLaunchKernelGGL((k_og_shadow_offgrid<true, true>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, PT_OGS_ARGS);
                         else hipLaunchKernelGGL((k_og_shadow_offgrid<false, true>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, PT_OGS_ARGS);
@@ -1249,6 +1265,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
 #undef PT_OGS_ARGS
 #undef PT_LAUNCH_ACP
 #undef PT_LAUNCH_AC
+#undef PT_LAUNCH_SHADE_P
 #undef PT_LAUNCH_SHADE_G
 #undef PT_LAUNCH_SHADE
 #undef PT_SHADE_ARGS
@@ -1319,7 +1336,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
                                  c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes,
                                  c.trace_nodes, c.trace_tris, c.shadow_skipped, c.bounce0_hits, c.bounce0_shadow_rays,
-                                 c.bounce0_tris, c.grid_tris};
+                                 c.bounce0_tris, c.grid_tris, c.bounce0_cam_tris};
 #ifdef WF_EXIT_TIMES
         {   // diagnostic build: when did the wavefronts of every k_wf_trace launch run out of queue / exit? (us after launch start)
             std::unique_ptr<DevCounters> full(new DevCounters);

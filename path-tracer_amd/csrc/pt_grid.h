@@ -140,13 +140,15 @@ PT_D bool og_blocked(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, 
 // get_light_info (mod.rs:281-333) for light `li` through its grid: the radiance that reaches the surface (pos,
 // normal gn, uv, kind).  Point light: cube map around the light, looked up with (pos - light); the caller has checked
 // that |gn| is within the grid's margin.  Directional light: orthographic grid, looked up with the ray's origin.
-template <bool ALPHA, bool COUNT>
+// DIRL: the scene has directional lights (a compile-time switch: the orthographic branch compiled into the fused
+// bounce-0 kernel costs it 112 B more scratch per lane and 3.5 ms on config 3, which has none).
+template <bool ALPHA, bool COUNT, bool DIRL>
 PT_D f3 og_light_radiance(const DevScene& S, uint32_t li, f3 pos, f3 gn, f2 uv, bool sphere, LocalCtr& lc) {
     const DevLight& L = S.lights[li];
     const DevGrid& G = S.light_grids[li];
     const f3 so = pos + gn * 0.00001f;   // NORMAL_BIAS (mod.rs:58)
     if (COUNT) lc.shadow_rays++;
-    if (L.kind != PT_LIGHT_POINT) {   // mod.rs:283-299: every hit of the whole ray counts, sampled at ITS surface
+    if (DIRL && L.kind != PT_LIGHT_POINT) {   // mod.rs:283-299: every hit of the whole ray counts, sampled at ITS surface
         const f3 sd = -1.f * ld3(L.vec);
         f3 rad = ld3(L.color);
         const uint32_t cell = og_cell_ortho(G, so);

@@ -92,7 +92,7 @@ PT_D void og_retire(f3 color, uint32_t next_idx, uint32_t out_slot, float4* __re
 // Used for bounces >= 1: there a lean kernel of its own (60 registers, 8 waves per SIMD) next to the 128-register
 // shade kernel beats casting inline (MI355X, config 3, bounce 1: 3.66 + 0.74 ms against 5.98 ms).
 // ---------------------------------------------------------------------------
-template <bool ALPHA, bool COUNT>
+template <bool ALPHA, bool COUNT, bool DIRL>
 __global__ __launch_bounds__(256) void k_og_shadow(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
                                                    const float4* __restrict__ contrib, float4* __restrict__ queue_next,
                                                    float* __restrict__ staging, uint32_t* __restrict__ offgrid,
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_og_shadow(DevScene S, WfParams W, const
                 }
                 continue;
             }
-            const f3 rad = og_light_radiance<ALPHA, COUNT>(S, li, pos, gn, uv, sphere, lc);
+            const f3 rad = og_light_radiance<ALPHA, COUNT, DIRL>(S, li, pos, gn, uv, sphere, lc);
             if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) color = color + mul_ew(term, rad);
         }
         og_retire(color, __float_as_uint(s2.w), __float_as_uint(s3.x), queue_next, staging);

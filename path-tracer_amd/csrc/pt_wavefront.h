@@ -841,8 +841,9 @@ PT_D bool wf_light_is_moot(const DevLight& L, f3 term, f3 surface_pos) {
 // 3 - (bounce 0) 2 + the item's ChaCha12 block is computed HERE instead of by k_wf_rng: the ~800 integer
 //     instructions per item run underneath the memory latency of the casts, and only the paths that go on write
 //     the words of bounces 1 and 2 (plane 1 of the RNG planes; a path has made at least four draws by then).
-template <bool ALPHA, bool COUNT, bool PRIMARY, int GRID>
-__global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_SHADE_WAVES) void k_wf_shade(DevScene S, WfParams W,
+// GRIDX = GRID + 4 * DIRL; DIRL: some light is directional (orthographic grid branch of og_light_radiance compiled in).
+template <bool ALPHA, bool COUNT, bool PRIMARY, int GRIDX>
+__global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_SHADE_WAVES) void k_wf_shade(DevScene S, WfParams W,
                                                   const uint32_t* __restrict__ tile_offsets,
                                                   const float4* __restrict__ queue_in, const uint4* __restrict__ hits,
                                                   const uint4* rng_planes,
@@ -850,6 +851,9 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
                                                   float4* __restrict__ queue_out, float4* __restrict__ shadow_q,
                                                   float4* __restrict__ contrib, float* __restrict__ staging,
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
+    constexpr int GRID = GRIDX & 3;
+    constexpr bool DIRL = GRIDX >= 4;
+    static_assert(GRIDX != 4, "DIRL needs a grid mode");
     uint4* rng_planes_out = const_cast<uint4*>(rng_planes);   // GRID == 3 writes plane 1 (nobody reads it before bounce 1)
     static_assert(GRID < 2 || PRIMARY, "the camera grid serves bounce 0");
     const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
@@ -994,7 +998,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
                 if (moot) {
                     if (COUNT) n_moot++;
                 } else {
-                    const f3 rad = og_light_radiance<ALPHA, COUNT>(S, li, surf.pos, surf.normal, surf.uv, surf.sphere, lc);
+                    const f3 rad = og_light_radiance<ALPHA, COUNT, DIRL>(S, li, surf.pos, surf.normal, surf.uv, surf.sphere, lc);
                     if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) color = color + mul_ew(c, rad);
                 }
             } else if (!moot) {
@@ -1183,6 +1187,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRID ? WF_SHADE_GRID_WAVES : WF_S
         atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
         if (GRID >= 2) {
             atomicAdd(&gctr->trace_tris, (unsigned long long)n_cam_tris);
+            atomicAdd(&gctr->bounce0_cam_tris, (unsigned long long)n_cam_tris);
             atomicAdd(&gctr->bounce0_tris, (unsigned long long)lc.tris);
             atomicAdd(&gctr->bounce0_shadow_rays, (unsigned long long)lc.shadow_rays);
         }
