@@ -305,6 +305,7 @@ typedef struct pt_counters {
     uint64_t bounce0_tris;         /* primitive tests of that kernel (camera casts + shadow casts)    */
     uint64_t grid_tris;            /* of tris_tested: made through origin grids (camera / point lights) */
     uint64_t bounce0_cam_tris;     /* of bounce0_tris: the camera casts (also part of trace_tris)       */
+    uint64_t deferred_casts;       /* closest-hit casts finished by k_wf_trace_wide (drain phase of k_wf_trace) */
 } pt_counters;
 
 int pt_get_timing(const pt_scene* scene, pt_timing* out);

@@ -473,7 +473,7 @@ struct pt_scene {
     // The queues of the chunk of work items in flight.  The shadow casts of bounce b run on a side stream
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
-        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid;
+        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid, deferred;
         hipStream_t side = nullptr, side_rng = nullptr;
         hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr;
     };
@@ -877,7 +877,12 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         accum = (float*)s.accum_scratch.p;
     }
     const bool timing = o.flags & PT_FLAG_TIMING, counting = o.flags & PT_FLAG_COUNTERS;
-    if (counting) {
+#ifdef WF_EXIT_TIMES
+    const bool exit_times = true;    // diagnostic build: the stamps are taken by the plain (non-counting) kernels too
+#else
+    const bool exit_times = false;
+#endif
+    if (counting || exit_times) {
         s.counter_buf.ensure(sizeof(DevCounters));
         HIP_CHECK(hipMemsetAsync(s.counter_buf.p, 0, sizeof(DevCounters), stream));
 #ifdef WF_EXIT_TIMES
@@ -937,6 +942,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         // later bounces (7.9 against 8.2 ms per 64 spp, MI355X, config 3)
         return (uint32_t)(e && *e ? atoi(e) : 0);
     }();
+    static const uint32_t wf_defer = [] {   // k_wf_trace: age (loop iterations) at which a cast leaves a drained wavefront
+        const char* e = getenv("PT_WF_DEFER");
+        return (uint32_t)(e && *e ? atoi(e) : 8);
+    }();
     static const uint32_t wf_refill_shadow = [] {
         const char* e = getenv("PT_WF_REFILL_SHADOW");
         return (uint32_t)(e && *e ? atoi(e) : 0);
@@ -995,12 +1004,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       w.contrib.try_ensure((size_t)cap * 16u * lights) && w.rng[0].try_ensure((size_t)cap * 32u) &&
                       (!(multi_chunk && wf_overlap) || w.rng[1].try_ensure((size_t)cap * 32u)) &&
                       (!alpha || w.draws.try_ensure((size_t)cap * 4u)) &&   // RNG draw index of the alpha walk
-                      (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u));   // surfaces left to the KD-tree
+                      (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u)) &&   // surfaces left to the KD-tree
+                      (alpha || !wf_defer || w.deferred.try_ensure((size_t)cap * 4u));   // casts left to k_wf_trace_wide
             if (ok) {
                 if (multi_chunk) s.wf_cap_ok = cap;   // (a frame that fits in one chunk says nothing about larger ones)
                 break;
             }
-            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1], &w.draws, &w.offgrid})
+            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1], &w.draws, &w.offgrid, &w.deferred})
                 b->release();
             if (cap <= (1u << 20))
                 fail(PT_ERR_DEVICE, "out of device memory: the path queues need %zu bytes for %u work items",
@@ -1036,7 +1046,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         ++stage_launches;
         if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stage_stream));
     };
-    DevCounters* gctr = counting ? (DevCounters*)s.counter_buf.p : nullptr;
+    DevCounters* gctr = (counting || exit_times) ? (DevCounters*)s.counter_buf.p : nullptr;
     for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
         P.sample_begin = s0;
         P.sample_end = std::min(p.samples, s0 + batch);
@@ -1189,8 +1199,14 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
 #undef PT_LAUNCH_OGP
                             HIP_CHECK(hipGetLastError());
                         } else {
+                            W.defer_age = (prim || alpha) ? 0u : wf_defer;
                             PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
-                                          (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, wctr, gctr);
+                                          (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (uint32_t*)pipe.deferred.p, wctr, gctr);
+                            if (W.defer_age) {   // the casts the drained wavefronts handed over (pt_wavefront.h)
+                                if (counting) hipLaunchKernelGGL((k_wf_trace_wide<true>), dim3((uint32_t)s.n_cu * 4u), dim3(WF_THREADS), 0, st_main, s.dev, W, (const float4*)q_in, (uint4*)pipe.hits.p, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
+                                else hipLaunchKernelGGL((k_wf_trace_wide<false>), dim3((uint32_t)s.n_cu * 4u), dim3(WF_THREADS), 0, st_main, s.dev, W, (const float4*)q_in, (uint4*)pipe.hits.p, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
+                                HIP_CHECK(hipGetLastError());
+                            }
                         }
                         stage_end();
                         ++launches;
@@ -1306,7 +1322,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     }
     if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
 
-    if (timing || counting) HIP_CHECK(hipStreamSynchronize(stream));
+    if (timing || counting || exit_times) HIP_CHECK(hipStreamSynchronize(stream));
     if (timing) {
         pt_timing t{};
         t.launches = launches;
@@ -1330,33 +1346,40 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         HIP_CHECK(hipEventElapsedTime(&t.total_ms, s.events[0], s.events[ev_post + 1]));
         s.timing = t;
     }
+#ifdef WF_EXIT_TIMES
+    {   // diagnostic build: when did the wavefronts of every k_wf_trace launch run out of queue / exit? (us after launch start)
+        std::unique_ptr<DevCounters> full(new DevCounters);
+        HIP_CHECK(hipMemcpy(full.get(), s.counter_buf.p, sizeof(DevCounters), hipMemcpyDeviceToHost));
+        for (int b = 0; b < 8; ++b) {
+            std::vector<double> ex, qd;
+            for (int w = 0; w < 8192; ++w)
+                if (full->wave_exit[b][w]) {
+                    ex.push_back((double)(full->wave_exit[b][w] - full->launch_start[b]) / 100.0);
+                    if (full->wave_queue_done[b][w]) qd.push_back((double)(full->wave_queue_done[b][w] - full->launch_start[b]) / 100.0);
+                }
+            if (ex.empty()) continue;
+            std::sort(ex.begin(), ex.end());
+            std::sort(qd.begin(), qd.end());
+            auto q = [](const std::vector<double>& v, double f) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+            fprintf(stderr, "[pt] trace bounce %d: %zu waves | queue exhausted (us) p1 %.0f p50 %.0f p99 %.0f max %.0f | exit p1 %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f\n",
+                    b, ex.size(), q(qd, 0.01), q(qd, 0.5), q(qd, 0.99), qd.empty() ? 0.0 : qd.back(), q(ex, 0.01), q(ex, 0.1), q(ex, 0.5), q(ex, 0.9), q(ex, 0.99), q(ex, 0.999), ex.back());
+        }
+    }
+#endif
     if (counting) {
         DevCounters c;
         HIP_CHECK(hipMemcpy(&c, s.counter_buf.p, sizeof c, hipMemcpyDeviceToHost));
         s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
                                  c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes,
                                  c.trace_nodes, c.trace_tris, c.shadow_skipped, c.bounce0_hits, c.bounce0_shadow_rays,
-                                 c.bounce0_tris, c.grid_tris, c.bounce0_cam_tris};
-#ifdef WF_EXIT_TIMES
-        {   // diagnostic build: when did the wavefronts of every k_wf_trace launch run out of queue / exit? (us after launch start)
-            std::unique_ptr<DevCounters> full(new DevCounters);
-            HIP_CHECK(hipMemcpy(full.get(), s.counter_buf.p, sizeof(DevCounters), hipMemcpyDeviceToHost));
-            for (int b = 0; b < 8; ++b) {
-                std::vector<double> ex, qd;
-                for (int w = 0; w < 8192; ++w)
-                    if (full->wave_exit[b][w]) {
-                        ex.push_back((double)(full->wave_exit[b][w] - full->launch_start[b]) / 100.0);
-                        if (full->wave_queue_done[b][w]) qd.push_back((double)(full->wave_queue_done[b][w] - full->launch_start[b]) / 100.0);
-                    }
-                if (ex.empty()) continue;
-                std::sort(ex.begin(), ex.end());
-                std::sort(qd.begin(), qd.end());
-                auto q = [](const std::vector<double>& v, double f) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
-                fprintf(stderr, "[pt] trace bounce %d: %zu waves | queue exhausted (us) p1 %.0f p50 %.0f p99 %.0f max %.0f | exit p1 %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f\n",
-                        b, ex.size(), q(qd, 0.01), q(qd, 0.5), q(qd, 0.99), qd.empty() ? 0.0 : qd.back(), q(ex, 0.01), q(ex, 0.1), q(ex, 0.5), q(ex, 0.9), q(ex, 0.99), q(ex, 0.999), ex.back());
-            }
+                                 c.bounce0_tris, c.grid_tris, c.bounce0_cam_tris, c.deferred_casts};
+        if (getenv("PT_DEBUG_HIST")) {   // casts of k_wf_trace by length (bins of 64 node visits; bin 0 not counted)
+            fprintf(stderr, "[pt] cast length histogram (x64 nodes):");
+            for (int b = 1; b < 16; ++b) fprintf(stderr, " %llu", c.cast_hist[b]);
+            fprintf(stderr, "\n[pt] wide casts %llu: rounds total %llu max %llu | node steps %llu | time per cast (us): mean %.1f max %.1f\n",
+                    c.deferred_casts, c.stamps[0], c.stamps[1], c.stamps[3],
+                    c.deferred_casts ? (double)c.stamps[5] / 100.0 / (double)c.deferred_casts : 0.0, (double)c.stamps[4] / 100.0);
         }
-#endif
         if (getenv("PT_DEBUG_STAMPS"))
             fprintf(stderr, "[pt] trace stamps: refill %llu walk %llu leaf %llu complete %llu cycles | walk lanes/step %.1f (%llu steps) | leaf lanes/run %.1f (%llu runs)\n",
                     c.stamps[0], c.stamps[1], c.stamps[2], c.stamps[3], c.stamps[5] ? (double)c.stamps[4] / c.stamps[5] : 0.0,

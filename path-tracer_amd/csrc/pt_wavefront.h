@@ -73,6 +73,7 @@ struct WfParams {
     uint32_t refill_min;  // idle lanes that trigger a queue refill in the persistent kernels
     uint32_t walk_steps;  // node steps per walking phase
     uint32_t sort_octants;  // k_wf_shade buckets the survivors of a workgroup step by direction octant
+    uint32_t defer_age;     // k_wf_trace, queue exhausted: casts older than this many loop iterations go to k_wf_trace_wide (0: never)
 };
 
 #ifndef WF_CURSORS
@@ -87,6 +88,7 @@ struct WfCounters {  // one set per bounce level, zeroed once per chunk
     uint32_t trace_work[WF_CURSORS * WF_CURSOR_STRIDE];
     uint32_t shadow_work[WF_CURSORS * WF_CURSOR_STRIDE];
     uint32_t offgrid_count;  // shadow records k_og_shadow left to k_og_shadow_offgrid (pt_grid_kernels.h)
+    uint32_t deferred_count; // casts k_wf_trace left to k_wf_trace_wide in its drain phase
 };
 
 #define WF_FLAG_TERMINATED 1u
@@ -330,25 +332,29 @@ PT_D bool trav_pop(Trav& T, const TravStack& st, float limit) {
 // costs an s_and_saveexec / s_cbranch pair, and the scalar unit is shared by the 20 waves of a CU —
 // the branchy form of this step was ~110 instructions, more than half of them scalar mask juggling,
 // and took ~4400 cycles per wave-step whatever the scene size (profiles/r01_f_trace_stamps.txt).
-template <bool COUNT>
-PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float limit, LocalCtr& lc) {
+PT_D uint2 trav_node(const DevScene& S, uint32_t node, const TravStack& st) {
 #if WF_LDS_NODES > 0
     // Deep lanes fetch from memory, all lanes read the (clamped) LDS slot, and the two results are merged
     // with explicit selects: they must sit in different registers, or the compiler serialises the two
     // fetches (one waits for the other's destination registers).
-    const bool is_deep = T.node >= (uint32_t)WF_LDS_NODES;
+    const bool is_deep = node >= (uint32_t)WF_LDS_NODES;
     const unsigned long long deep = __builtin_amdgcn_ballot_w64(is_deep);
     uint2 g;
     asm volatile("" : "=v"(g.x), "=v"(g.y));   // (lanes that do not load keep whatever is there: they select the LDS word)
-    if (is_deep) g = S.kd_nodes[T.node];
-    const uint32_t top_slot = T.node < (uint32_t)WF_LDS_NODES ? T.node : (uint32_t)WF_LDS_NODES - 1u;
+    if (is_deep) g = S.kd_nodes[node];
+    const uint32_t top_slot = node < (uint32_t)WF_LDS_NODES ? node : (uint32_t)WF_LDS_NODES - 1u;
     const unsigned long long e = st.top[top_slot];
     uint2 nd;
     nd.x = __float_as_uint(wf_select(deep, __uint_as_float(g.x), __uint_as_float((uint32_t)e)));
     nd.y = __float_as_uint(wf_select(deep, __uint_as_float(g.y), __uint_as_float((uint32_t)(e >> 32))));
+    return nd;
 #else
-    const uint2 nd = S.kd_nodes[T.node];
+    return S.kd_nodes[node];
 #endif
+}
+template <bool COUNT>
+PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float limit, LocalCtr& lc) {
+    const uint2 nd = trav_node(S, T.node, st);
     if (COUNT) lc.nodes++;
     const uint32_t axis = nd.y & 3u;
     if (axis != 3u) {
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
                                                          const uint32_t* __restrict__ tile_offsets,
                                                          float4* __restrict__ queue, uint4* __restrict__ hits,
                                                          const uint4* __restrict__ rng_planes,
-                                                         uint32_t* __restrict__ draws,
+                                                         uint32_t* __restrict__ draws, uint32_t* __restrict__ deferred,
                                                          WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
     __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
 #endif
     wf_load_tree_top(S, lds_top);
 #ifdef WF_EXIT_TIMES
-    if (COUNT && threadIdx.x == 0 && W.bounce < 8) atomicMin(&gctr->launch_start[W.bounce], __builtin_amdgcn_s_memrealtime());
+    if (gctr && threadIdx.x == 0 && W.bounce < 8) atomicMin(&gctr->launch_start[W.bounce], __builtin_amdgcn_s_memrealtime());
     unsigned long long t_queue_done = 0;
 #endif
     const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
@@ -619,6 +625,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
                 uint32_t nn = lc.nodes - cast_nodes0;
                 atomicMax(&gctr->max_nodes_per_cast, (unsigned long long)nn);
                 if (nn > 1000u) atomicAdd(&gctr->casts_over_1k_nodes, 1ull);
+                if (nn >= 64u) atomicAdd(&gctr->cast_hist[nn / 64u < 15u ? nn / 64u : 15u], 1ull);
             }
             if (ALPHA && !hit && have_kept) {  // every hit skipped: the last one is shaded
                 best = kept;
@@ -697,7 +704,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
         }
         WF_STAMP(st_refill);
 #ifdef WF_EXIT_TIMES
-        if (COUNT && wf.done && !t_queue_done) t_queue_done = __builtin_amdgcn_s_memrealtime();
+        if (wf.done && !t_queue_done) t_queue_done = __builtin_amdgcn_s_memrealtime();
 #endif
         if (!__any(active)) {
             if (__all(exhausted)) break;
@@ -770,6 +777,24 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
         WF_STAMP(st_leaf);
         if (lstate == WF_LANE_DONE) complete();
         WF_STAMP(st_done);
+        // ---- drain phase: once the queue has nothing left for this wavefront, a cast that has been going for
+        // defer_age iterations is handed to k_wf_trace_wide (16 lanes per cast) instead of keeping the wavefront - and,
+        // at the end, the whole launch - waiting for one lane: the last 1 % of the wavefronts of a launch used to leave
+        // 0.2 ... 0.5 ms after the median one, a fifth of the launch for an eighth of a 1080p frame.
+        if (!ALPHA && !PRIMARY && W.defer_age != 0u) {
+            T.dneg += 8u;   // (bits 3 and up: the age of the cast in loop iterations; trav_start sets the register afresh)
+            if (wf.done && wf.cur >= wf.end) {
+                const bool defer = active && T.dneg >= W.defer_age * 8u;
+                if (wf_any(defer)) {
+                    const uint32_t slot = wf_reserve(&ctr[W.bounce].deferred_count, defer);
+                    if (defer) {
+                        deferred[slot] = idx;
+                        active = false;
+                        lstate = WF_LANE_IDLE;
+                    }
+                }
+            }
+        }
     }
 #ifdef WF_STAMPS
     if (COUNT && (threadIdx.x & 63u) == 0) {
@@ -784,7 +809,7 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
     }
 #endif
 #ifdef WF_EXIT_TIMES
-    if (COUNT && (threadIdx.x & 63u) == 0 && W.bounce < 8) {
+    if (gctr && (threadIdx.x & 63u) == 0 && W.bounce < 8) {
         const uint32_t w = blockIdx.x * (WF_THREADS / 64u) + (threadIdx.x >> 6);
         if (w < 8192u) {
             gctr->wave_exit[W.bounce][w] = __builtin_amdgcn_s_memrealtime();
@@ -801,6 +826,199 @@ __global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES 
         atomicAdd(&gctr->trace_tris, (unsigned long long)lc.tris);
         if (ALPHA) atomicAdd(&gctr->shaded_hits, (unsigned long long)lc.shaded);
         if (ALPHA) atomicAdd(&gctr->rng_draws, (unsigned long long)lc.shadow_rays);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The casts k_wf_trace handed over in its drain phase, WF_WIDE_LANES lanes per cast.  The group walks ONE tree
+// traversal together, in rounds (the wavefront runs in lock step: ballots and lane ranks, no atomics):
+//   * a lane without a segment takes the next one from its own stack; lanes that still have none are fed by lanes
+//     that have pending segments on theirs (one each, through a pool in LDS);
+//   * every lane with a segment walks up to WF_WIDE_STEPS nodes, stopping at a non-empty leaf;
+//   * the leaves reached in the round are tested by the whole group, lane p taking primitive p of each (the ray is
+//     the group's, so any lane can test any primitive; all record loads of a leaf are in flight together).
+// The cast's hit is the smallest (distance, order) any lane found.  The same answer as the one-lane walk: the accepted
+// hit is the minimum of a total order over ALL intersected primitives, whichever lane tests them, and the group visits
+// every leaf the one-lane walk visits, except those beyond a hit already found (segments are culled against the
+// group's best distance with the traversal's usual slack; a handed-over segment starts no later than recorded).
+// ---------------------------------------------------------------------------
+#ifndef WF_WIDE_LANES
+#define WF_WIDE_LANES 16u
+#endif
+#ifndef WF_WIDE_STEPS
+#define WF_WIDE_STEPS 2u
+#endif
+#define WF_WIDE_LIST 64u   // leaf records a group lists per round
+template <bool COUNT>
+__global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevScene S, WfParams W, const float4* __restrict__ queue,
+                                                                            uint4* __restrict__ hits,
+                                                                            const uint32_t* __restrict__ deferred,
+                                                                            const WfCounters* __restrict__ ctr,
+                                                                            DevCounters* __restrict__ gctr) {
+    constexpr uint32_t L = WF_WIDE_LANES, GROUPS = WF_THREADS / L;
+    __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
+    __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
+    __shared__ uint32_t pool_node[GROUPS][L];          // segments handed over in this round ...
+    __shared__ float pool_tmin[GROUPS][L], pool_tmax[GROUPS][L];
+    __shared__ uint32_t leaf_list[GROUPS][WF_WIDE_LIST];   // ... and the leaf records reached in it
+    const uint32_t n = ctr[W.bounce].deferred_count;
+    if (n == 0u) return;   // (the usual case for a launch with a short queue)
+    wf_load_tree_top(S, lds_top);
+    uint32_t ov_node[PT_KD_STACK - WF_LDS_STACK];
+    float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
+    const TravStack st = {(wf_lds_u64*)(lds_stack + threadIdx.x), ov_node, ov_tmax, (const wf_lds_u64*)lds_top};
+    const uint32_t group = threadIdx.x / L, part = threadIdx.x & (L - 1u), lane = threadIdx.x & 63u;
+    const unsigned long long group_mask = ((1ull << L) - 1ull) << (lane & ~(L - 1u));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};
+    // (whole wavefronts stay in the loops together: ballots and shuffles are wave-wide)
+    const uint32_t passes = (n + gridDim.x * GROUPS - 1u) / (gridDim.x * GROUPS);
+    for (uint32_t r = 0; r < passes; ++r) {
+        const uint32_t e = (r * gridDim.x + blockIdx.x) * GROUPS + group;
+        const uint32_t idx = e < n ? deferred[e] : 0u;
+        RawHit best;
+        best.key = INFINITY;
+        best.ord = 0xffffffffu;
+        best.pid = 0xffffffffu;
+        best.u = best.v = 0.f;
+        best.flags = 0u;
+        Trav T;
+        bool in_scene = false;
+        if (e < n) {
+            const float4* q = queue + (size_t)idx * 4;
+            const float4 q0 = q[0], q1 = q[1];
+            in_scene = trav_start(S, T, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), 0.f);
+        }
+        bool busy = in_scene && part == 0u;   // the root segment; the other lanes live off what is handed over
+        uint32_t dbg_rounds = 0, dbg_busy = 0;
+        const unsigned long long dbg_t0 = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        while (true) {
+            if (COUNT) dbg_rounds++;
+            // the group's best distance so far: what every lane culls against
+            float gkey = best.key;
+#pragma unroll
+            for (uint32_t m = L / 2u; m >= 1u; m >>= 1) {
+                const float k2 = __shfl_xor(gkey, (int)m);
+                gkey = k2 < gkey ? k2 : gkey;
+            }
+            // a lane without a segment goes on with its own stack (nothing left within gkey: the rest is dropped) ...
+            if (in_scene && !busy && T.sp > 0) {
+                busy = trav_pop(T, st, gkey);
+                if (!busy) T.sp = 0;
+            }
+            // ... or is handed the nearest pending segment of a lane that has one
+            const bool need = in_scene && !busy;
+            if (wf_any(need)) {
+                const bool can_give = busy && T.sp > 0;
+                const unsigned long long m_need = __ballot(need) & group_mask, m_give = __ballot(can_give) & group_mask;
+                const uint32_t n_need = (uint32_t)__popcll(m_need), n_can = (uint32_t)__popcll(m_give);
+                const uint32_t n_give = n_need < n_can ? n_need : n_can;
+                if (can_give && (uint32_t)__popcll(m_give & below) < n_give) {
+                    const uint32_t slot = (uint32_t)__popcll(m_give & below);
+                    uint32_t node;
+                    float tmax;
+                    --T.sp;
+                    stack_get(st, T.sp, node, tmax);
+                    pool_node[group][slot] = node;
+                    pool_tmin[group][slot] = T.tmax;   // (its true start if nothing nearer was handed over before: never later)
+                    pool_tmax[group][slot] = tmax;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (need && (uint32_t)__popcll(m_need & below) < n_give) {
+                    const uint32_t slot = (uint32_t)__popcll(m_need & below);
+                    T.node = pool_node[group][slot];
+                    T.tmin = pool_tmin[group][slot];
+                    T.tmax = pool_tmax[group][slot];
+                    T.sp = 0;
+                    busy = !(T.tmin * T.key_scale > gkey * PT_EXIT_REL + PT_EXIT_ABS);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (!wf_any(busy)) break;   // (a lane without a segment has an empty stack: the casts of this wavefront are done)
+            // up to WF_WIDE_STEPS nodes
+            bool at_leaf = false;
+            for (uint32_t k = 0; k < WF_WIDE_STEPS; ++k) {
+                if (busy && !at_leaf) {
+                    if (COUNT) dbg_busy++;
+                    const uint32_t state = trav_step<COUNT>(S, T, st, gkey, lc);
+                    at_leaf = state == WF_LANE_LEAF;
+                    busy = state != WF_LANE_DONE;
+                    if (!busy) T.sp = 0;
+                }
+            }
+            // the leaves reached: tested by the group together - the records of ALL of them are listed in LDS and lane p
+            // takes entries p, p + L, ... of the list, so one round costs one trip to memory for its leaves
+            if (wf_any(at_leaf)) {
+                const uint32_t my_count = at_leaf ? T.leaf.y >> 2 : 0u;
+                uint32_t incl = my_count;
+#pragma unroll
+                for (uint32_t m = 1u; m < L; m <<= 1) {
+                    const uint32_t up = __shfl_up(incl, (int)m);
+                    if (part >= m) incl += up;
+                }
+                const uint32_t total = __shfl(incl, (int)((lane & ~(L - 1u)) + L - 1u));
+                if (at_leaf) {
+                    const uint32_t off = incl - my_count;
+                    for (uint32_t j = 0; j < my_count; ++j)
+                        if (off + j < WF_WIDE_LIST) leaf_list[group][off + j] = T.leaf.x + j;
+                    busy = false;   // (its next segment: from the stack, in the next round)
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t listed = total < WF_WIDE_LIST ? total : WF_WIDE_LIST;
+                for (uint32_t i = part; i < listed; i += L) {
+                    const float4* rec = S.leaf_prims + (size_t)leaf_list[group][i] * 3;
+                    og_test_closest<COUNT>(T.o, T.d, rec[0], rec[1], rec[2], -INFINITY, 0u, best, lc);
+                }
+                if (__builtin_expect(wf_any(total > WF_WIDE_LIST), 0)) {   // (more records than the list holds: the owners test the rest)
+                    if (at_leaf) {
+                        const uint32_t off = incl - my_count;
+                        for (uint32_t j = 0; j < my_count; ++j)
+                            if (off + j >= WF_WIDE_LIST) {
+                                const float4* rec = S.leaf_prims + (size_t)(T.leaf.x + j) * 3;
+                                og_test_closest<COUNT>(T.o, T.d, rec[0], rec[1], rec[2], -INFINITY, 0u, best, lc);
+                            }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (COUNT && e < n) {   // diagnostics (PT_DEBUG_HIST): rounds per cast, node steps
+            if (part == 0u) atomicAdd(&gctr->stamps[0], (unsigned long long)dbg_rounds);
+            if (part == 0u) atomicMax(&gctr->stamps[1], (unsigned long long)dbg_rounds);
+            atomicAdd(&gctr->stamps[3], (unsigned long long)dbg_busy);
+            if (part == 0u) atomicMax(&gctr->stamps[4], __builtin_amdgcn_s_memrealtime() - dbg_t0);
+            if (part == 0u) atomicAdd(&gctr->stamps[5], __builtin_amdgcn_s_memrealtime() - dbg_t0);
+        }
+        // the group's minimum of (key, ord)
+        float kmin = best.key;
+        uint32_t omin = best.ord;
+#pragma unroll
+        for (uint32_t m = L / 2u; m >= 1u; m >>= 1) {
+            const float k2 = __shfl_xor(kmin, (int)m);
+            const uint32_t o2 = __shfl_xor(omin, (int)m);
+            if (key_less(k2, o2, kmin, omin)) {
+                kmin = k2;
+                omin = o2;
+            }
+        }
+        const bool found = best.pid != 0xffffffffu && best.key == kmin && best.ord == omin;
+        const unsigned long long winners = __ballot(found) & group_mask;
+        if (e < n) {
+            if (winners) {
+                if (lane == (uint32_t)__ffsll((long long)winners) - 1u) hits[idx] = pack_hit(best, true);
+            } else if (part == 0u) {
+                hits[idx] = pack_hit(best, false);
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&gctr->nodes_visited, (unsigned long long)lc.nodes);
+        atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->trace_nodes, (unsigned long long)lc.nodes);
+        atomicAdd(&gctr->trace_tris, (unsigned long long)lc.tris);
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&gctr->deferred_casts, (unsigned long long)n);
     }
 }
 

@@ -536,6 +536,11 @@ def test_config3_full_size(pta, oracle, ps5_scene):
     assert np.isfinite(acc).all() and rgb.max() > 0
     # (b) oracle rows: top, two through the model, bottom (ground plane)
     _oracle_rows_equal(pta, oracle, scene, prof, acc, rgb, (0, 431, 540, 1079))
+    # the drain phase of the persistent trace launches handed casts to k_wf_trace_wide (16 lanes per cast), and the
+    # whole frame equals the megakernel's, which walks every cast with one lane from start to end
+    assert c["deferred_casts"] > 0
+    rgb_m, acc_m = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_MEGAKERNEL))
+    assert np.array_equal(bits(acc_m), bits(acc)) and np.array_equal(rgb_m, rgb)
     # (a) any partition of the samples: three batches of 48 / 48 / 32
     rgb_b, acc_b = g.render(prof, pta.Opts.make(sample_batch=48))
     assert np.array_equal(bits(acc_b), bits(acc)) and np.array_equal(rgb_b, rgb)
