@@ -944,7 +944,22 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     }();
     static const uint32_t wf_defer = [] {   // k_wf_trace: age (loop iterations) at which a cast leaves a drained wavefront
         const char* e = getenv("PT_WF_DEFER");
-        return (uint32_t)(e && *e ? atoi(e) : 8);
+        return (uint32_t)(e && *e ? atoi(e) : 16);
+    }();
+    // k_wf_shade: workgroups per CU in the grid.  The kernel's loops are grid-stride, but a grid of just the resident
+    // workgroups (3 per CU) keeps the whole chip on ONE window of the image at a time - everybody in the ChaCha-bound
+    // background together, then everybody waiting for casts into the model together.  Many more workgroups than are
+    // resident, each with a short loop, mix the two (and balance the end): bounce-0 kernel of config 3, 3 / 16 / 64 /
+    // 256 / 1024 / 4096 workgroups per CU: 20.9 / 17.3 / 16.1 / 15.5 / 15.4 / 16.4 ms; the later bounces (queues of
+    // unknown, shrinking length: every extra workgroup is a dispatch that may find nothing) are best at 32
+    // (16 / 32 / 64 / 128: frame 37.6 / 36.2 / 36.2 / 36.2 ms, one shard of eight 5.97 / 5.92 / 6.03 / 6.13 ms).
+    static const uint32_t shade_blocks_b0 = [] {
+        const char* e = getenv("PT_SHADE_BLOCKS_B0");
+        return (uint32_t)(e && *e ? atoi(e) : 256);
+    }();
+    static const uint32_t shade_blocks_later = [] {
+        const char* e = getenv("PT_SHADE_BLOCKS");
+        return (uint32_t)(e && *e ? atoi(e) : 32);
     }();
     static const uint32_t wf_refill_shadow = [] {
         const char* e = getenv("PT_WF_REFILL_SHADOW");
@@ -1165,8 +1180,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     s.dev, W, d_tiles, (const float4*)q_in, (const uint4*)pipe.hits.p, (const uint4*)rng_planes, (const uint32_t*)pipe.draws.p, \
         q_out, (float4*)pipe.shadow.p, (float4*)pipe.contrib.p, (float*)s.staging_buf.p, wctr, gctr
 #define PT_LAUNCH_SHADE(A, C, P, G)                                                                                    \
-    hipLaunchKernelGGL((k_wf_shade<A, C, P, G>), dim3((uint32_t)(s.n_cu * 4 * (1024 / WF_SHADE_THREADS))),             \
-                       dim3(WF_SHADE_THREADS), 0, st_main, PT_SHADE_ARGS)
+    hipLaunchKernelGGL((k_wf_shade<A, C, P, G>), dim3(shade_grid), dim3(WF_SHADE_THREADS), 0, st_main, PT_SHADE_ARGS)
 #define PT_LAUNCH_SHADE_G(G)                                                   \
     do {                                                                       \
         if (prim && alpha && counting) PT_LAUNCH_SHADE(true, true, true, G);   \
@@ -1213,6 +1227,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     }
                     // shade(b) reads the colours shadow(b-1) patched and refills the shadow queue it consumed
                     if (st_shadow != st_main && b > 0) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
+                    // (no more workgroups than the chunk has 256-entry steps)
+                    const uint32_t shade_grid = std::max(1u, std::min((uint32_t)s.n_cu * (prim ? shade_blocks_b0 : shade_blocks_later),
+                                                                      (W.n_items + WF_SHADE_THREADS - 1u) / WF_SHADE_THREADS));
                     if (timing && grid_mode >= 2) fused_marks.push_back(ev);
                     stage_begin(2);
                     // (+4: the variants with the orthographic branch for directional lights compiled in)

@@ -41,12 +41,12 @@ def find(table, fragment):
 
 def test_hot_kernels_stay_within_their_register_and_scratch_budgets(tmp_path):
     t = kernel_table(tmp_path)
-    # the fused bounce-0 kernel of opaque scenes without directional lights (config 3): 4 waves / SIMD
+    # the fused bounce-0 kernel of opaque scenes without directional lights (config 3): 3 waves / SIMD, (almost) no scratch
     b0 = find(t, "k_wf_shadeILb0ELb0ELb1ELi3EE")
-    assert b0["vgpr_count"] <= 128 and b0["private_segment_fixed_size"] <= 160, b0
+    assert b0["vgpr_count"] <= 170 and b0["private_segment_fixed_size"] <= 32, b0
     # ... and of translucent scenes (config 5)
     b0a = find(t, "k_wf_shadeILb1ELb0ELb1ELi3EE")
-    assert b0a["vgpr_count"] <= 128 and b0a["private_segment_fixed_size"] <= 260, b0a
+    assert b0a["vgpr_count"] <= 170 and b0a["private_segment_fixed_size"] <= 80, b0a
     # shading of the later bounces
     sh = find(t, "k_wf_shadeILb0ELb0ELb0ELi0EE")
     assert sh["vgpr_count"] <= 128 and sh["private_segment_fixed_size"] <= 96, sh
