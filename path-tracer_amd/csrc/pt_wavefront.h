@@ -1052,12 +1052,6 @@ PT_D bool wf_light_is_moot(const DevLight& L, f3 term, f3 surface_pos) {
 // 132 B of its state per lane in scratch: 18.66 ms against 17.09 ms at 3 (and 21.3 ms at 2) on config 3.
 #define WF_SHADE_GRID_WAVES 3
 #endif
-#ifndef WF_B0_AGGREGATE
-// Fused bounce-0 kernel (GRID 3): cast 256 camera rays, retire the misses, shade the hits 256 at a time out of 64-byte
-// records in LDS.  Measured (bit-identical): 17.27 ms against 17.03 ms without at 3 waves per SIMD, 20.8 against 18.7 ms
-// at 4 (240 B of scratch) - the kernel waits for its casts more than for its vector unit.  Off.
-#define WF_B0_AGGREGATE 0
-#endif
 // GRID (origin grids, pt_grid.h): 0 - none: direct light goes through the shadow queue and k_wf_shadow / k_og_shadow;
 // 1 - every light is a point light with a grid: get_light_info (mod.rs:281-333) is evaluated HERE, light after
 //     light, so a surface costs no shadow record, no contrib entries and no colour patch (190 B of queue traffic
@@ -1089,16 +1083,11 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
     __shared__ uint32_t sh_base[2];
     __shared__ uint32_t sh_oct[8][WF_SHADE_THREADS / 64], sh_oct_off[8][WF_SHADE_THREADS / 64];
     const uint32_t wave = threadIdx.x >> 6;
-    // Bounce 0, fused (GRID 3): 44 % of the camera rays of config 3 leave into the background, so shading item by item
-    // ran the material fetch, the BRDF, the GGX sample and the shadow casts - half of the kernel's instructions - at
-    // 56 % of the lanes.  Instead a first pass does the ChaCha block and the camera cast (+ alpha walk) of 256 items
-    // with every lane busy, retires the misses and leaves a 64-byte record per hit in LDS; whenever 256 records are
-    // waiting - or the items have run out - they are shaded together (b0_rec: hit | RNG words 2-7, screen position |
-    // item, output slot, draws).  The order in which paths are shaded is free, so no bit changes.
-    constexpr bool B0AGG = PRIMARY && GRID == 3 && WF_B0_AGGREGATE != 0;
-    __shared__ uint4 b0_rec[4][B0AGG ? 2 * WF_SHADE_THREADS : 1];
+    // (Bounce 0 needs no hit aggregation like the later bounces' below: a wavefront is one 8x8 pixel block of one sample,
+    // so its camera rays hit or miss together - collecting the hits of 256 items in LDS and shading them 256 at a time left
+    // the instruction count and the 52 active lanes per instruction unchanged, profiles/r02_experiments.txt item 13.)
     // One workgroup-wide step: thread t shades queue entry i (live = it has one).  Every thread of the workgroup
-    // calls this together: the compaction at the end has barriers.  (B0AGG: i is the record's place in b0_rec.)
+    // calls this together: the compaction at the end has barriers.
     auto shade_one = [&](const uint32_t i, bool live) {
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), color = mk3(0, 0, 0);
     uint32_t item = i, draw = 0, out_slot = 0;
@@ -1120,20 +1109,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
         word = idx == 7u ? later_words.w : word;
         return wf_rng_float(word);
     };
-    if (B0AGG && live) {   // the state the first pass left
-        const uint4 r0 = b0_rec[0][i], r1 = b0_rec[1][i], r2 = b0_rec[2][i], r3 = b0_rec[3][i];
-        hit = unpack_hit(r0, h);
-        word2 = r1.x;
-        word3 = r1.y;
-        later_words = make_uint4(r1.z, r1.w, r2.x, r2.y);
-        primary_from_screen(S, __uint_as_float(r2.z), __uint_as_float(r2.w), o, d);
-        item = r3.x;
-        out_slot = r3.y;
-        draw = r3.z;
-        thr = mk3(1.f, 1.f, 1.f);
-        color = mk3(0.f, 0.f, 0.f);
-    }
-    if (PRIMARY && !B0AGG && live) {  // entry i is work item i: the initial path state, built in place
+    if (PRIMARY && live) {  // entry i is work item i: the initial path state, built in place
         ItemRef it = decode_item(W.P, tile_offsets, W.item_base + i);
         if (!it.valid) {
             live = false;
@@ -1364,109 +1340,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
                              : draw - (ALPHA ? draws[i] : PRIMARY ? 0u : (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu)) +
                                    ((ALPHA && PRIMARY) ? 2u : 0u);
     };  // shade_one
-    if (B0AGG) {
-        __shared__ uint32_t b0_cnt[WF_SHADE_THREADS / 64];
-        uint32_t have = 0;   // waiting records (the same value in every thread)
-        uint32_t base = blockIdx.x * WF_SHADE_THREADS;
-        while (true) {
-            while (have < WF_SHADE_THREADS && base < n) {
-                const uint32_t i = base + threadIdx.x;
-                base += gridDim.x * WF_SHADE_THREADS;
-                bool is_hit = false;
-                uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0, r2 = r0, r3 = r0;
-                ItemRef it;
-                it.valid = false;
-                if (i < n) it = decode_item(W.P, tile_offsets, W.item_base + i);
-                if (it.valid) {   // StdRng::seed_from_u64(sample + i * samples), jitter x then y (mod.rs:110-120)
-                    const uint32_t out_slot = (it.sample - 1u - W.P.sample_begin) * W.P.n_local + it.out_index;
-                    uint32_t w[16];
-                    pt_chacha12_block((uint64_t)it.sample + (uint64_t)it.global_index * (uint64_t)W.P.samples, 0u, w);
-                    float sx, sy;
-                    primary_screen(S, it.x, it.y, W.P.width, W.P.height, wf_rng_float(w[0]), wf_rng_float(w[1]), sx, sy);
-                    f3 o, d;
-                    primary_from_screen(S, sx, sy, o, d);
-                    // ray_cast + alpha walk of the camera ray (mod.rs:182-205) through the camera grid
-                    const uint32_t cell = og_cell(S.cam_grid, d);
-                    const float dlen = mag3(d);
-                    const float kmax = (dlen > 1.0f ? dlen : 1.0f) * 1.00002f;
-                    uint32_t draw = 2u;   // the pixel jitter
-                    if (COUNT) lc.segments++;
-                    const uint32_t tris_before = lc.tris;
-                    RawHit h;
-                    bool hit = og_next_hit<COUNT>(S, S.cam_grid, cell, o, d, kmax, INFINITY, -INFINITY, 0u, h, lc);
-                    if (ALPHA) {
-                        RawHit kept = h;
-                        bool have_kept = false;
-                        WfRng rng;   // (draws past word 7 - more than three alpha draws - derive the block again)
-                        rng.block = 0xffffffffu;
-                        while (hit) {
-                            const float opacity = hit_opacity(S, o, d, h);
-                            if (COUNT) lc.shaded++;
-                            bool stop = opacity >= 1.f;
-                            if (!stop && opacity > 0.001f) {
-                                const uint32_t k = draw++;   // (selects, not w[k]: a dynamic index would put the block in scratch)
-                                uint32_t word = w[2];
-                                word = k == 3u ? w[3] : word;
-                                word = k == 4u ? w[4] : word;
-                                word = k == 5u ? w[5] : word;
-                                word = k == 6u ? w[6] : word;
-                                word = k == 7u ? w[7] : word;
-                                const float r = k < WF_RNG_STAGED ? wf_rng_float(word) : wf_rng_draw(rng, W, tile_offsets, rng_planes, i, k);
-                                stop = r < opacity;
-                            }
-                            if (stop) break;
-                            kept = h;   // skipped: remember it, look for the next entry of the list
-                            have_kept = true;
-                            if (COUNT) lc.restarts++;
-                            hit = og_next_hit<COUNT>(S, S.cam_grid, cell, o, d, kmax, INFINITY, kept.key, kept.ord, h, lc);
-                        }
-                        if (!hit && have_kept) {   // every hit skipped: the last one is shaded
-                            h = kept;
-                            hit = true;
-                        }
-                    }
-                    if (COUNT) {
-                        n_cam_tris += lc.tris - tris_before;
-                        n_new++;
-                    }
-                    if (hit) {
-                        is_hit = true;
-                        r0 = pack_hit(h, true);
-                        r1 = make_uint4(w[2], w[3], w[4], w[5]);
-                        r2 = make_uint4(w[6], w[7], __float_as_uint(sx), __float_as_uint(sy));
-                        r3 = make_uint4(i, out_slot, draw, 0u);
-                    } else {  // background (mod.rs:184-186): the path ends here
-                        const f3 c = mk3(0.f, 0.f, 0.f) + mul_ew(mk3(1.f, 1.f, 1.f), ld3(S.background));
-                        float* out = staging + (size_t)out_slot * 3;
-                        out[0] = c.x;
-                        out[1] = c.y;
-                        out[2] = c.z;
-                        if (COUNT) n_draws += draw;
-                    }
-                }
-                const unsigned long long m = __ballot(is_hit);
-                if ((threadIdx.x & 63u) == 0) b0_cnt[wave] = (uint32_t)__popcll(m);
-                __syncthreads();
-                uint32_t pos = have + wf_lane_rank(m), total = 0;
-                for (uint32_t k = 0; k < WF_SHADE_THREADS / 64; ++k) {
-                    if (k < wave) pos += b0_cnt[k];
-                    total += b0_cnt[k];
-                }
-                if (is_hit) {
-                    b0_rec[0][pos] = r0;
-                    b0_rec[1][pos] = r1;
-                    b0_rec[2][pos] = r2;
-                    b0_rec[3][pos] = r3;
-                }
-                have += total;
-                __syncthreads();
-            }
-            if (have == 0) break;
-            const uint32_t take = have < WF_SHADE_THREADS ? have : (uint32_t)WF_SHADE_THREADS;
-            have -= take;
-            shade_one(have + threadIdx.x, threadIdx.x < take);
-        }
-    } else if (PRIMARY || !WF_SHADE_AGGREGATE) {
+    if (PRIMARY || !WF_SHADE_AGGREGATE) {
         // grid-stride over the queue, one workgroup-wide step at a time (the loop bound is uniform in the workgroup)
         for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS)
             shade_one(base + threadIdx.x, base + threadIdx.x < n);
