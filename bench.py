@@ -255,10 +255,18 @@ def main():
             try:
                 rec = json.loads(tf.read_text())
                 if rec.get("workload") == [args.tris, args.width, args.height, args.spp, args.bounces, world] and \
-                        rec.get("kernel", "").split("<")[0] == name.split("<")[0].split(" ")[0] and not args.opt_flags:
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    valu_rate = rec.get("valu_insts_per_cu_cycle")
-                    traffic_src = f"profiles/latest_traffic.json <- {rec.get('source')}"
+                        not args.opt_flags and not args.scene_flags:
+                    short = name.split("<")[0].split(" ")[0]   # k_wf_shade / k_wf_trace / k_og_shadow
+                    per_kernel = rec.get("kernels", {})
+                    key = next((k for k in per_kernel if k.split("<")[0] == short and ("GRID" in k) == ("<GRID>" in name)), None)
+                    if key is not None:
+                        traffic = per_kernel[key].get("hbm_bytes_per_launch")
+                        valu_rate = per_kernel[key].get("valu_insts_per_cu_cycle")
+                        traffic_src = f"profiles/latest_traffic.json <- {rec.get('source')} ({key})"
+                    elif rec.get("kernel", "").split("<")[0] == short:
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        valu_rate = rec.get("valu_insts_per_cu_cycle")
+                        traffic_src = f"profiles/latest_traffic.json <- {rec.get('source')}"
             except Exception:
                 traffic = None
         copy_gbs = pta.measure_copy_bandwidth(local_rank, 2 << 30, 5)   # achievable HBM rate on this box

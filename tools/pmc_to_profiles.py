@@ -59,6 +59,10 @@ json.dump({"workload": workload, "kernel": dominant, "hbm_bytes_per_launch": rou
            "tcp_accesses_per_cu_cycle": t["tcp_accesses_per_cu_cycle"],
            "valu_insts_per_cu_cycle": t["valu_insts_per_cu_cycle"],
            "active_lanes_per_valu_inst": t["active_lanes_per_valu_inst"],
+           # every kernel's figures: bench.py reports the one with the largest time in ITS run, which may differ
+           "kernels": {k: {"hbm_bytes_per_launch": round(v["hbm_bytes_per_launch"]),
+                           "valu_insts_per_cu_cycle": v["valu_insts_per_cu_cycle"],
+                           "active_lanes_per_valu_inst": v["active_lanes_per_valu_inst"]} for k, v in out.items()},
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_profile.sh); bytes = "
                      "(2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per 128 B "
                      "request); calibration in this pipeline: k_accumulate reads 12 B/sample -> FETCH_SIZE reads 0.48x",
