@@ -72,7 +72,7 @@ struct WfParams {
     uint32_t bounce;      // current bounce (shade / shadow)
     uint32_t refill_min;  // idle lanes that trigger a queue refill in the persistent kernels
     uint32_t walk_steps;  // node steps per walking phase
-    uint32_t sort_octants;  // k_wf_shade buckets the survivors of a workgroup step by direction octant
+    uint32_t sort_octants;  // k_wf_shade: bit 0 - survivors of a workgroup step bucketed by direction octant; bit 1 - hits shaded in material order
     uint32_t defer_age;     // k_wf_trace, queue exhausted: casts older than this many loop iterations go to k_wf_trace_wide (0: never)
 };
 
@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
     // record in a queue is free (results are keyed by out_slot), so no bit of the image changes.
     unsigned long long m_next = __ballot(survive), m_sh = __ballot(to_shadow);
     uint32_t oct = 0, oct_rank = 0;
-    if (W.sort_octants) {
+    if (W.sort_octants & 1u) {
         oct = (next_d.x < 0.f ? 1u : 0u) | (next_d.y < 0.f ? 2u : 0u) | (next_d.z < 0.f ? 4u : 0u);
 #pragma unroll
         for (uint32_t k = 0; k < 8u; ++k) {
@@ -1291,7 +1291,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
         for (uint32_t k = 0; k < WF_SHADE_THREADS / 64; ++k) total += sh_cnt[threadIdx.x][k];
         uint32_t* counter = threadIdx.x == 0 ? &ctr[bounce + 1].queue_count : &ctr[bounce].shadow_count;
         sh_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
-    } else if (W.sort_octants && threadIdx.x >= 64u && threadIdx.x < 64u + 8u * (WF_SHADE_THREADS / 64)) {
+    } else if ((W.sort_octants & 1u) && threadIdx.x >= 64u && threadIdx.x < 64u + 8u * (WF_SHADE_THREADS / 64)) {
         // exclusive prefix of the (octant, wave) counts, octant-major
         const uint32_t e = threadIdx.x - 64u;
         uint32_t before = 0;
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
         next_idx += sh_cnt[0][k];
         sh_idx += sh_cnt[1][k];
     }
-    if (W.sort_octants) next_idx = sh_base[0] + sh_oct_off[oct][wave] + oct_rank;
+    if (W.sort_octants & 1u) next_idx = sh_base[0] + sh_oct_off[oct][wave] + oct_rank;
     __syncthreads();  // sh_cnt / sh_base are rewritten by the next step
     if (GRID == 3 && survive) rng_planes_out[(size_t)W.cap + item] = later_words;   // draws 4-7 of the path
     if (survive) {
@@ -1391,8 +1391,37 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
             if (have == 0) break;
             const uint32_t take = have < WF_SHADE_THREADS ? have : (uint32_t)WF_SHADE_THREADS;
             have -= take;
-            const uint32_t mine = threadIdx.x < take ? agg[have + threadIdx.x] : 0u;
+            uint32_t mine = threadIdx.x < take ? agg[have + threadIdx.x] : 0u;
             __syncthreads();
+            if (W.sort_octants & 2u) {
+                // Material sorting (measured option, PT_WF_SORT=2): the 256 hits of a step are ordered by the model -
+                // i.e. the material - of the primitive they hit (8 classes, stable counting sort: ballot per class,
+                // mbcnt rank, prefix over classes and waves in LDS), so that a wavefront shades one material's
+                // texture set.  The order in which paths are shaded is free: no bit changes.
+                __shared__ uint32_t agg_sorted[WF_SHADE_THREADS];
+                uint32_t key = 8u, rank = 0u;
+                if (threadIdx.x < take) {
+                    const uint32_t prim = hits[mine].x & 0x0fffffffu;
+                    key = __float_as_uint(S.prim_attr[(size_t)prim * 4 + 3].w) & 7u;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; ++k) {
+                    const unsigned long long m = __ballot(key == k);
+                    if ((threadIdx.x & 63u) == 0) sh_oct[k][wave] = (uint32_t)__popcll(m);
+                    if (key == k) rank = wf_lane_rank(m);
+                }
+                __syncthreads();
+                if (threadIdx.x < 8u * (WF_SHADE_THREADS / 64)) {
+                    uint32_t before = 0;
+                    for (uint32_t j = 0; j < threadIdx.x; ++j) before += sh_oct[j / (WF_SHADE_THREADS / 64)][j % (WF_SHADE_THREADS / 64)];
+                    sh_oct_off[threadIdx.x / (WF_SHADE_THREADS / 64)][threadIdx.x % (WF_SHADE_THREADS / 64)] = before;
+                }
+                __syncthreads();
+                if (threadIdx.x < take) agg_sorted[sh_oct_off[key][wave] + rank] = mine;
+                __syncthreads();
+                mine = threadIdx.x < take ? agg_sorted[threadIdx.x] : 0u;
+                __syncthreads();
+            }
             shade_one(mine, threadIdx.x < take);
         }
     }
