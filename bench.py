@@ -147,13 +147,21 @@ def main():
                                  "integrate_ms", "total_ms", "bounce0_ms")}
     launches = {"launches": 0, "stage_launches": 0, "bounce0_launches": 0}
 
-    def step():
-        gscene.render_device(prof, opts, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
-        tm = gscene.timing().as_dict()
-        for k in stage_ms:
-            stage_ms[k] += tm[k]
-        for k in launches:
-            launches[k] += tm[k]
+    # HIP events around every launch (PT_FLAG_TIMING: ~36 event records and one host synchronisation per frame): on every
+    # timed step of the one-GPU run; on the FIRST timed step only when the frame is sharded - a rank's frame is a few
+    # milliseconds there, and the other steps are enqueued without a host round trip, as a renderer would run them
+    opts_plain = pta.Opts.make(flags=args.opt_flags, device=local_rank, shard_rank=rank, shard_count=world,
+                               tile_w=tile, tile_h=tile)
+    ev_steps = max(1, args.steps if world == 1 else 1)
+
+    def step(with_events=True):
+        gscene.render_device(prof, opts if with_events else opts_plain, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
+        if with_events:
+            tm = gscene.timing().as_dict()
+            for k in stage_ms:
+                stage_ms[k] += tm[k]
+            for k in launches:
+                launches[k] += tm[k]
         if world > 1:
             if args.backend == "nccl":
                 dist.all_gather_into_tensor(gathered, rgb_local)   # RCCL over xGMI, one exchange per frame
@@ -177,8 +185,8 @@ def main():
         launches[k] = 0
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(with_events=k < ev_steps)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -207,11 +215,11 @@ def main():
         kernels = {}
         if launches["bounce0_launches"]:
             # the fused bounce-0 kernel (k_wf_shade<GRID >= 2>): ChaCha block, camera cast, shading, shadow casts
-            per_frame = launches["bounce0_launches"] // args.steps
+            per_frame = launches["bounce0_launches"] // ev_steps
             b0_bytes = (n_items * 160 + counters["bounce0_shadow_rays"] * 104 + counters["bounce0_tris"] * 36
                         + counters["bounce0_hits"] * 160 + n_items * 12)
             kernels["k_wf_shade<GRID> (bounce 0: ChaCha12 block + camera cast + shading + shadow casts)"] = dict(
-                ms_per_frame=stage_ms["bounce0_ms"] / args.steps, launches_per_frame=per_frame,
+                ms_per_frame=stage_ms["bounce0_ms"] / ev_steps, launches_per_frame=per_frame,
                 bytes_per_frame=b0_bytes, units_per_launch=n_items // max(1, per_frame), unit="path samples")
         fused = bool(launches["bounce0_launches"])
         trace_segments = counters["segments"] - (n_items if fused else 0)
@@ -219,8 +227,8 @@ def main():
         trace_tris = counters["trace_tris"] - (counters["bounce0_cam_tris"] if fused else 0)
         trace_bytes = trace_segments * 80 + counters["trace_nodes"] * 8 + trace_tris * 36
         kernels["k_wf_trace (closest-hit KD-tree casts)"] = dict(
-            ms_per_frame=stage_ms["integrate_ms"] / args.steps, launches_per_frame=trace_launches // args.steps,
-            bytes_per_frame=trace_bytes, units_per_launch=trace_segments // max(1, trace_launches // args.steps),
+            ms_per_frame=stage_ms["integrate_ms"] / ev_steps, launches_per_frame=trace_launches // ev_steps,
+            bytes_per_frame=trace_bytes, units_per_launch=trace_segments // max(1, trace_launches // ev_steps),
             unit="ray casts")
         # the shadow casts outside the fused kernel (k_og_shadow through the light grids, k_wf_shadow on the KD-tree):
         # 104 B per ray cast + its node visits and primitive tests
@@ -229,12 +237,12 @@ def main():
             ((counters["bounce0_tris"] - counters["bounce0_cam_tris"]) if fused else 0)
         sh_nodes = counters["nodes_visited"] - counters["trace_nodes"]
         # (one shadow stage per bounce iteration, i.e. per closest-hit launch or fused bounce-0 launch)
-        sh_launches = max(1, (launches["launches"] + launches["bounce0_launches"]) // args.steps)
+        sh_launches = max(1, (launches["launches"] + launches["bounce0_launches"]) // ev_steps)
         if sh_rays > 0 and stage_ms["shadow_ms"] > 0:
             sh_name = "k_og_shadow (shadow casts through the light grids)" if info["light_grids"] and \
                 not (args.opt_flags & pta.PT_FLAG_NO_GRIDS) else "k_wf_shadow (any-hit KD-tree casts)"
             kernels[sh_name] = dict(
-                ms_per_frame=stage_ms["shadow_ms"] / args.steps, launches_per_frame=sh_launches,
+                ms_per_frame=stage_ms["shadow_ms"] / ev_steps, launches_per_frame=sh_launches,
                 bytes_per_frame=sh_rays * 104 + sh_nodes * 8 + sh_tris * 36,
                 units_per_launch=sh_rays // sh_launches, unit="shadow rays",
                 # HIP events on the side stream: the launches share the chip with k_wf_trace of the next bounce, so this
@@ -245,7 +253,7 @@ def main():
         bytes_per_launch = dom["bytes_per_frame"] / max(1, dom["launches_per_frame"])
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # wall time of the kernel pipeline (shadow casts may overlap the next trace, so the stages do not add up)
-        kernel_total = stage_ms["total_ms"] / args.steps
+        kernel_total = stage_ms["total_ms"] / ev_steps
         pipeline = ceil_b * n_items / (kernel_total * 1e-3) / 1e9
         # HBM traffic from the PMC passes (separate rocprofv3 --pmc runs, tools/pmc_profile.sh): not measured in this
         # run - read from the committed summary of the same workload and code, and labelled as such
@@ -278,7 +286,7 @@ def main():
                     # what the kernel actually runs against (PMC): vector-instruction issue, 1.0 per CU-cycle = the ceiling
                     "valu_insts_per_cu_cycle": valu_rate,
                     "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
-                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": dom["launches_per_frame"],
+                    "avg_launch_ms": round(avg_ms, 4), "steps_timed_with_events": ev_steps, "launches_per_step": dom["launches_per_frame"],
                     "units_per_launch": dom["units_per_launch"], "unit_name": dom["unit"],
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
                     "algorithmic_bytes_per_unit": round(bytes_per_launch / max(1, dom["units_per_launch"]), 1),
@@ -295,7 +303,7 @@ def main():
                                                            / HBM_PEAK_GBS, 5),
                                  "Grays_per_s": round((counters["segments"] + counters["shadow_rays"]
                                                        - counters["shadow_skipped"]) / (kernel_total * 1e-3) / 1e9, 3)},
-                    "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
+                    "stage_ms_per_step": {k: round(v / ev_steps, 3) for k, v in stage_ms.items()},
                     "per_sample": {k: round(v, 3) for k, v in per.items()}}
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only)
