@@ -1020,7 +1020,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       (!(multi_chunk && wf_overlap) || w.rng[1].try_ensure((size_t)cap * 32u)) &&
                       (!alpha || w.draws.try_ensure((size_t)cap * 4u)) &&   // RNG draw index of the alpha walk
                       (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u)) &&   // surfaces left to the KD-tree
-                      (alpha || !wf_defer || w.deferred.try_ensure((size_t)cap * 4u));   // casts left to k_wf_trace_wide
+                      // casts left to k_wf_trace_wide: at most one per lane in flight when the queue runs dry
+                      (alpha || !wf_defer || w.deferred.try_ensure((size_t)s.trace_blocks * WF_THREADS * 4u));
             if (ok) {
                 if (multi_chunk) s.wf_cap_ok = cap;   // (a frame that fits in one chunk says nothing about larger ones)
                 break;
