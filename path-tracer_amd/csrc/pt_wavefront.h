@@ -984,6 +984,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
                 __builtin_amdgcn_wave_barrier();
             }
         }
+#ifndef WF_STAMPS   // (a -DWF_STAMPS build keeps its phase cycles in the same slots)
         if (COUNT && e < n) {   // diagnostics (PT_DEBUG_HIST): rounds per cast, node steps
             if (part == 0u) atomicAdd(&gctr->stamps[0], (unsigned long long)dbg_rounds);
             if (part == 0u) atomicMax(&gctr->stamps[1], (unsigned long long)dbg_rounds);
@@ -991,6 +992,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
             if (part == 0u) atomicMax(&gctr->stamps[4], __builtin_amdgcn_s_memrealtime() - dbg_t0);
             if (part == 0u) atomicAdd(&gctr->stamps[5], __builtin_amdgcn_s_memrealtime() - dbg_t0);
         }
+#endif
         // the group's minimum of (key, ord)
         float kmin = best.key;
         uint32_t omin = best.ord;
