@@ -118,6 +118,17 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
     }
 }
 
+// The three 16-byte words of a primitive record, as one batch of loads.  Without this the compiler sinks the loads of
+// e1.yz / e2 into the triangle branch (a sphere only needs the first five words), so that the common case - a triangle -
+// pays TWO dependent trips to memory per test; the traversal kernels are bound by exactly those trips.
+PT_D void load_prim_record(const float4* __restrict__ rec, float4& q0, float4& q1, float4& q2) {
+    q0 = rec[0];
+    q1 = rec[1];
+    q2 = rec[2];
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
+                      "+v"(q2.x), "+v"(q2.y));
+}
+
 // Triangle::intersect on a leaf record (v0, e1, e2).  Returns true and fills
 // (dist, u, v, backface) on a hit.
 PT_D bool isect_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& dist, float& u, float& v, bool& backface) {

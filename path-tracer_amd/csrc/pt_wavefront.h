@@ -197,7 +197,10 @@ PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursors, uint32_t n, bool need
 // takes the stack traffic off the vector-memory path (it was 2 GB of HBM writes per 33 M rays).
 // ---------------------------------------------------------------------------
 #ifndef WF_LDS_STACK
-#define WF_LDS_STACK 8
+// 14 entries (28 KB per workgroup; with the 2 KB tree top five workgroups still share a CU's 160 KB).  With 8, the
+// overflow into scratch was 12 % of the trace kernel's vector-L1 accesses (PMC: 9.69 G at 8, 8.54 G at 12, 15.1 G at 4
+// entries), and those accesses are what the kernel is bound by: frame 36.40 -> 35.47 ms at 11 entries.
+#define WF_LDS_STACK 14
 #endif
 #ifndef WF_THREADS
 #define WF_THREADS 256
@@ -206,7 +209,7 @@ PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursors, uint32_t n, bool need
 #define WF_MIN_WAVES 1   // minimum waves per SIMD the trace/shadow kernels are compiled for
 #endif
 #ifndef WF_PRIMARY_WAVES
-#define WF_PRIMARY_WAVES 5   // the bounce-0 trace is held to the register budget of the other bounces
+#define WF_PRIMARY_WAVES 5   // the bounce-0 trace and the opaque trace are held to 96 registers (they fit without spilling)
 #endif
 
 struct Trav {
@@ -233,7 +236,7 @@ struct TravStack {
 // hit L1 or not (profiles/r01_f_trace_stamps.txt), and every ray passes through the top levels, so the
 // first node slots - the device layout is breadth-first over 4-level treelets - are read from LDS.
 #ifndef WF_LDS_NODES
-#define WF_LDS_NODES 1024
+#define WF_LDS_NODES 256   // (the top eight levels; 1024 nodes with an 11-entry stack measured 0.7 % slower than 256 with 14)
 #endif
 PT_D void wf_load_tree_top(const DevScene& S, unsigned long long* lds_top) {
     if (WF_LDS_NODES == 0) return;
@@ -413,7 +416,8 @@ PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_pre
     const float4* lp = S.leaf_prims + (size_t)leaf.x * 3;
     uint32_t n = leaf.y >> 2;
     for (uint32_t i = 0; i < n; ++i) {
-        float4 q0 = lp[3 * i];
+        float4 q0, q1, q2;
+        load_prim_record(lp + 3 * i, q0, q1, q2);
         uint32_t pid = __float_as_uint(q0.w);
 #if WF_MAILBOX
         // a primitive is referenced from ~7 leaves: the one tested last need not be tested again (the acceptance rule
@@ -421,7 +425,6 @@ PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_pre
         if (pid == mailbox) continue;
         mailbox = pid;
 #endif
-        float4 q1 = lp[3 * i + 1], q2 = lp[3 * i + 2];
         if (COUNT) lc.tris++;
         if (!(pid & PT_PRIM_SPHERE)) {
             float dist, u, v;
@@ -555,7 +558,7 @@ PT_D float wf_rng_draw(WfRng& fb, const WfParams& W, const uint32_t* __restrict_
 // place from the screen position k_wf_rng staged (no 64 B/item ray record written and read back).  Translucent
 // scenes keep the number of rng.gen() calls of a path in draws[entry]: the alpha walk below may draw.
 template <bool ALPHA, bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(WF_THREADS, (PRIMARY && !COUNT) ? WF_PRIMARY_WAVES : WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W,
+__global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PRIMARY_WAVES : WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W,
                                                          const uint32_t* __restrict__ tile_offsets,
                                                          float4* __restrict__ queue, uint4* __restrict__ hits,
                                                          const uint4* __restrict__ rng_planes,
@@ -969,7 +972,9 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
                 const uint32_t listed = total < WF_WIDE_LIST ? total : WF_WIDE_LIST;
                 for (uint32_t i = part; i < listed; i += L) {
                     const float4* rec = S.leaf_prims + (size_t)leaf_list[group][i] * 3;
-                    og_test_closest<COUNT>(T.o, T.d, rec[0], rec[1], rec[2], -INFINITY, 0u, best, lc);
+                    float4 q0, q1, q2;
+                    load_prim_record(rec, q0, q1, q2);
+                    og_test_closest<COUNT>(T.o, T.d, q0, q1, q2, -INFINITY, 0u, best, lc);
                 }
                 if (__builtin_expect(wf_any(total > WF_WIDE_LIST), 0)) {   // (more records than the list holds: the owners test the rest)
                     if (at_leaf) {
@@ -977,7 +982,9 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
                         for (uint32_t j = 0; j < my_count; ++j)
                             if (off + j >= WF_WIDE_LIST) {
                                 const float4* rec = S.leaf_prims + (size_t)(T.leaf.x + j) * 3;
-                                og_test_closest<COUNT>(T.o, T.d, rec[0], rec[1], rec[2], -INFINITY, 0u, best, lc);
+                                float4 q0, q1, q2;
+                    load_prim_record(rec, q0, q1, q2);
+                    og_test_closest<COUNT>(T.o, T.d, q0, q1, q2, -INFINITY, 0u, best, lc);
                             }
                     }
                 }
@@ -1456,7 +1463,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
 // k_wf_trace; a job is one shaded surface, its lights are cast one after the other.
 // ---------------------------------------------------------------------------
 template <bool ALPHA, bool COUNT>
-__global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
+__global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES : WF_MIN_WAVES) void k_wf_shadow(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
                                                           const float4* __restrict__ contrib,
                                                           float4* __restrict__ queue_next, float* __restrict__ staging,
                                                           WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
@@ -1643,7 +1650,8 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_shadow(DevScene
                 const float4* lp = S.leaf_prims + (size_t)T.leaf.x * 3;
                 uint32_t np = T.leaf.y >> 2;
                 for (uint32_t i = 0; i < np && !blocked; ++i) {
-                    float4 q0 = lp[3 * i], q1 = lp[3 * i + 1], q2 = lp[3 * i + 2];
+                    float4 q0, q1, q2;
+                    load_prim_record(lp + 3 * i, q0, q1, q2);
                     uint32_t pid = __float_as_uint(q0.w);
                     if (COUNT) lc.tris++;
                     if (!(pid & PT_PRIM_SPHERE)) {
