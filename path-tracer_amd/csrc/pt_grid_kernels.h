@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_og_primary(DevScene S, WfParams W, cons
 }
 
 // A finished shadow job: the sample is complete (staging) or the colour of the path's next record is patched.
-PT_D void og_retire(f3 color, uint32_t next_idx, uint32_t out_slot, float4* __restrict__ queue_next,
+PT_D void og_retire(f3 color, uint32_t next_idx, uint32_t out_slot, float4* __restrict__ queue_next, uint32_t cap,
                     float* __restrict__ staging) {
     if (next_idx == 0xffffffffu) {
         float* out = staging + (size_t)out_slot * 3;
@@ -78,9 +78,7 @@ PT_D void og_retire(f3 color, uint32_t next_idx, uint32_t out_slot, float4* __re
         out[1] = color.y;
         out[2] = color.z;
     } else {
-        float4* q = queue_next + (size_t)next_idx * 4 + 2;
-        const float4 q2 = *q;
-        *q = make_float4(q2.x, color.x, color.y, color.z);
+        wf_path_rec(queue_next, cap, next_idx)[1] = make_float4(color.x, color.y, color.z, 0.f);
     }
 }
 
@@ -124,7 +122,7 @@ __global__ __launch_bounds__(256) void k_og_shadow(DevScene S, WfParams W, const
             const f3 rad = og_light_radiance<ALPHA, COUNT, DIRL>(S, li, pos, gn, uv, sphere, lc);
             if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) color = color + mul_ew(term, rad);
         }
-        og_retire(color, __float_as_uint(s2.w), __float_as_uint(s3.x), queue_next, staging);
+        og_retire(color, __float_as_uint(s2.w), __float_as_uint(s3.x), queue_next, W.cap, staging);
     }
     if (COUNT) {
         atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);
@@ -178,7 +176,7 @@ __global__ __launch_bounds__(256) void k_og_shadow_offgrid(DevScene S, WfParams 
             light_radiance<COUNT>(S, L, sf, rad, ldir, lc);
             if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) color = color + mul_ew(term, rad);
         }
-        og_retire(color, __float_as_uint(s2.w), __float_as_uint(s3.x), queue_next, staging);
+        og_retire(color, __float_as_uint(s2.w), __float_as_uint(s3.x), queue_next, W.cap, staging);
     }
     if (COUNT) {
         atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);

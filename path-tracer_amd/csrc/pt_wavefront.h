@@ -76,6 +76,15 @@ struct WfParams {
     uint32_t defer_age;     // k_wf_trace, queue exhausted: casts older than this many loop iterations go to k_wf_trace_wide (0: never)
 };
 
+// A path queue of capacity `cap` records is two planes of 32 bytes per record (the casts read the first only, the misses
+// of k_wf_shade the second only - that kernel runs at HBM speed):
+//   ray plane   q[2 i]     = (o.xyz, d.x)        q[2 i + 1]           = (d.y, d.z, item, draw | bounce << 16)
+//   path plane  q[2 cap + 2 i] = (thr.xyz, out_slot)  q[2 cap + 2 i + 1] = (colour.xyz, -)    <- patched by the shadow kernels
+PT_D const float4* wf_ray_rec(const float4* q, uint32_t i) { return q + (size_t)i * 2; }
+PT_D float4* wf_ray_rec(float4* q, uint32_t i) { return q + (size_t)i * 2; }
+PT_D const float4* wf_path_rec(const float4* q, uint32_t cap, uint32_t i) { return q + ((size_t)cap + i) * 2; }
+PT_D float4* wf_path_rec(float4* q, uint32_t cap, uint32_t i) { return q + ((size_t)cap + i) * 2; }
+
 #ifndef WF_CURSORS
 #define WF_CURSORS 8u   // fetch cursors per queue (a power of two)
 #endif
@@ -680,15 +689,14 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                     // (two 16-byte words of the record: these kernels run at the vector L1's request rate, ~0.97
                     // accesses per CU-cycle, so every load a ray does not need counts; queues past bounce 0 hold
                     // live paths only - items outside the image never leave the bounce-0 kernels)
-                    const float4* q = queue + (size_t)idx * 4;
+                    const float4* q = wf_ray_rec(queue, idx);
                     float4 q0 = q[0], q1 = q[1];
                     o = mk3(q0.x, q0.y, q0.z);
                     d = mk3(q0.w, q1.x, q1.y);
                     valid_item = true;
                     if (ALPHA) {
-                        float4 q3 = q[3];
-                        item = __float_as_uint(q3.x);
-                        draw = __float_as_uint(q3.y) & 0xffffu;
+                        item = __float_as_uint(q1.z);
+                        draw = __float_as_uint(q1.w) & 0xffffu;
                     }
                 }
                 if (COUNT && valid_item) lc.segments++;
@@ -888,7 +896,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
         Trav T;
         bool in_scene = false;
         if (e < n) {
-            const float4* q = queue + (size_t)idx * 4;
+            const float4* q = wf_ray_rec(queue, idx);
             const float4 q0 = q[0], q1 = q[1];
             in_scene = trav_start(S, T, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), 0.f);
         }
@@ -1180,15 +1188,16 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
         }
     }
     if (!PRIMARY && live) {
-        const float4* q = queue_in + (size_t)i * 4;
-        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        const float4* qr = wf_ray_rec(queue_in, i);
+        const float4* qp = wf_path_rec(queue_in, W.cap, i);
+        float4 q0 = qr[0], q1 = qr[1], q2 = qp[0], q3 = qp[1];
         o = mk3(q0.x, q0.y, q0.z);
         d = mk3(q0.w, q1.x, q1.y);
-        thr = mk3(q1.z, q1.w, q2.x);
-        color = mk3(q2.y, q2.z, q2.w);
-        item = __float_as_uint(q3.x);
-        draw = ALPHA ? draws[i] : (__float_as_uint(q3.y) & 0xffffu);
-        out_slot = __float_as_uint(q3.z);
+        thr = mk3(q2.x, q2.y, q2.z);
+        color = mk3(q3.x, q3.y, q3.z);
+        item = __float_as_uint(q1.z);
+        draw = ALPHA ? draws[i] : (__float_as_uint(q1.w) & 0xffffu);
+        out_slot = __float_as_uint(q2.w);
         hit = unpack_hit(hits[i], h);
         if (out_slot == 0xffffffffu) live = false;  // (records of items outside the image; none since bounce 0 is fused)
     }
@@ -1317,12 +1326,12 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
     __syncthreads();  // sh_cnt / sh_base are rewritten by the next step
     if (GRID == 3 && survive) rng_planes_out[(size_t)W.cap + item] = later_words;   // draws 4-7 of the path
     if (survive) {
-        float4* q = queue_out + (size_t)next_idx * 4;
-        q[0] = make_float4(next_o.x, next_o.y, next_o.z, next_d.x);
-        q[1] = make_float4(next_d.y, next_d.z, next_thr.x, next_thr.y);
-        q[2] = make_float4(next_thr.z, color.x, color.y, color.z);  // colour is patched by k_wf_shadow
-        q[3] = make_float4(__uint_as_float(item), __uint_as_float((draw & 0xffffu) | ((bounce + 1) << 16)),
-                           __uint_as_float(out_slot), 0.f);
+        float4* qr = wf_ray_rec(queue_out, next_idx);
+        float4* qp = wf_path_rec(queue_out, W.cap, next_idx);
+        qr[0] = make_float4(next_o.x, next_o.y, next_o.z, next_d.x);
+        qr[1] = make_float4(next_d.y, next_d.z, __uint_as_float(item), __uint_as_float((draw & 0xffffu) | ((bounce + 1) << 16)));
+        qp[0] = make_float4(next_thr.x, next_thr.y, next_thr.z, __uint_as_float(out_slot));
+        qp[1] = make_float4(color.x, color.y, color.z, 0.f);  // colour is patched by the shadow kernels
     }
     if (to_shadow) {
         float4* sq = shadow_q + (size_t)sh_idx * 4;
@@ -1346,7 +1355,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
     // draws made HERE (the alpha walk counts its own): since the value this kernel started from, plus the jitter
     if (COUNT && live)
         n_draws += GRID >= 2 ? draw
-                             : draw - (ALPHA ? draws[i] : PRIMARY ? 0u : (__float_as_uint(queue_in[(size_t)i * 4 + 3].y) & 0xffffu)) +
+                             : draw - (ALPHA ? draws[i] : PRIMARY ? 0u : (__float_as_uint(wf_ray_rec(queue_in, i)[1].w) & 0xffffu)) +
                                    ((ALPHA && PRIMARY) ? 2u : 0u);
     };  // shade_one
     if (PRIMARY || !WF_SHADE_AGGREGATE) {
@@ -1373,11 +1382,11 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
                 if (i < n) {
                     is_hit = hits[i].x != 0xffffffffu;
                     if (!is_hit) {
-                        const float4* q = queue_in + (size_t)i * 4;
-                        const float4 q1 = q[1], q2 = q[2], q3 = q[3];
-                        const uint32_t slot = __float_as_uint(q3.z);
+                        const float4* qp = wf_path_rec(queue_in, W.cap, i);
+                        const float4 q2 = qp[0], q3 = qp[1];
+                        const uint32_t slot = __float_as_uint(q2.w);
                         if (slot != 0xffffffffu) {
-                            const f3 c = mk3(q2.y, q2.z, q2.w) + mul_ew(mk3(q1.z, q1.w, q2.x), ld3(S.background));
+                            const f3 c = mk3(q3.x, q3.y, q3.z) + mul_ew(mk3(q2.x, q2.y, q2.z), ld3(S.background));
                             float* out = staging + (size_t)slot * 3;
                             out[0] = c.x;
                             out[1] = c.y;
@@ -1554,9 +1563,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
             out[1] = color.y;
             out[2] = color.z;
         } else {
-            float4* q = queue_next + (size_t)next_idx * 4 + 2;
-            float4 q2 = *q;
-            *q = make_float4(q2.x, color.x, color.y, color.z);
+            wf_path_rec(queue_next, W.cap, next_idx)[1] = make_float4(color.x, color.y, color.z, 0.f);
         }
         active = false;
     };
