@@ -1015,7 +1015,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             multi_chunk = (uint64_t)cap < items_per_batch;
             const size_t lights = std::max(1u, s.dev.n_lights);
             bool ok = w.queue[0].try_ensure((size_t)cap * 64u) && w.queue[1].try_ensure((size_t)cap * 64u) &&
-                      w.hits.try_ensure((size_t)cap * 16u) && w.shadow.try_ensure((size_t)cap * 64u) &&
+                      w.hits.try_ensure((size_t)cap * 20u) && w.shadow.try_ensure((size_t)cap * 64u) &&
                       w.contrib.try_ensure((size_t)cap * 16u * lights) && w.rng[0].try_ensure((size_t)cap * 32u) &&
                       (!(multi_chunk && wf_overlap) || w.rng[1].try_ensure((size_t)cap * 32u)) &&
                       (!alpha || w.draws.try_ensure((size_t)cap * 4u)) &&   // RNG draw index of the alpha walk

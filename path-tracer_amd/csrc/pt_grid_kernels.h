@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_og_primary(DevScene S, WfParams W, cons
             }
         }
     }
-    hits[i] = pack_hit(best, hit);
+    wf_store_hit(hits, W.cap, i, best, hit);
     if (ALPHA) draws[i] = draw;
     if (COUNT) {
         atomicAdd(&gctr->segments, (unsigned long long)lc.segments);

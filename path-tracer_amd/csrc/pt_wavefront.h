@@ -496,6 +496,21 @@ PT_D bool unpack_hit(uint4 r, RawHit& h) {
     return true;
 }
 
+// The hit records of a chunk, two planes (k_wf_shade's pass over the queue reads the first only; a miss writes the first
+// only): hits[i] as a 4-byte word - primitive | flags, 0xffffffff = no hit - for i < cap, then (key, u, v, -) per entry.
+PT_D uint32_t wf_hit_word(const uint4* hits, uint32_t i) { return ((const uint32_t*)hits)[i]; }
+PT_D void wf_store_hit(uint4* hits, uint32_t cap, uint32_t i, const RawHit& h, bool hit) {
+    const uint4 r = pack_hit(h, hit);
+    ((uint32_t*)hits)[i] = r.x;
+    if (hit) ((uint4*)((uint32_t*)hits + cap))[i] = make_uint4(r.y, r.z, r.w, 0u);
+}
+PT_D bool wf_load_hit(const uint4* hits, uint32_t cap, uint32_t i, RawHit& h) {
+    const uint32_t x = ((const uint32_t*)hits)[i];
+    if (x == 0xffffffffu) return false;
+    const uint4 k = ((const uint4*)((const uint32_t*)hits + cap))[i];
+    return unpack_hit(make_uint4(x, k.x, k.y, k.z), h);
+}
+
 PT_D float wf_rng_float(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0f); }  // rng.gen::<f32>()
 
 // ---------------------------------------------------------------------------
@@ -643,7 +658,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                 best = kept;
                 hit = true;
             }
-            hits[idx] = pack_hit(best, hit);
+            wf_store_hit(hits, W.cap, idx, best, hit);
             if (ALPHA) draws[idx] = draw;   // rng.gen() calls of the path so far (the alpha walk may have drawn)
             active = false;
             lstate = WF_LANE_IDLE;
@@ -1024,9 +1039,9 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
         const unsigned long long winners = __ballot(found) & group_mask;
         if (e < n) {
             if (winners) {
-                if (lane == (uint32_t)__ffsll((long long)winners) - 1u) hits[idx] = pack_hit(best, true);
+                if (lane == (uint32_t)__ffsll((long long)winners) - 1u) wf_store_hit(hits, W.cap, idx, best, true);
             } else if (part == 0u) {
-                hits[idx] = pack_hit(best, false);
+                wf_store_hit(hits, W.cap, idx, best, false);
             }
         }
     }
@@ -1178,7 +1193,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
                 if (COUNT) n_cam_tris += lc.tris - tris_before;
             } else {
                 draw = ALPHA ? draws[i] : 2u;   // 2 = the pixel jitter (+ the draws of the alpha walk)
-                hit = unpack_hit(hits[i], h);
+                hit = wf_load_hit(hits, W.cap, i, h);
                 if (hit) {  // (a missed cast only adds the background: no ray, no normalisation)
                     const uint2 sc = *(const uint2*)(rng_planes + i);  // jittered screen position (k_wf_rng)
                     primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
@@ -1198,7 +1213,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
         item = __float_as_uint(q1.z);
         draw = ALPHA ? draws[i] : (__float_as_uint(q1.w) & 0xffffu);
         out_slot = __float_as_uint(q2.w);
-        hit = unpack_hit(hits[i], h);
+        hit = wf_load_hit(hits, W.cap, i, h);
         if (out_slot == 0xffffffffu) live = false;  // (records of items outside the image; none since bounce 0 is fused)
     }
     const uint32_t bounce = PRIMARY ? 0u : W.bounce, bounces = W.P.bounces;   // (PRIMARY: no Russian roulette code at all)
@@ -1380,7 +1395,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
                 base += gridDim.x * WF_SHADE_THREADS;
                 bool is_hit = false;
                 if (i < n) {
-                    is_hit = hits[i].x != 0xffffffffu;
+                    is_hit = wf_hit_word(hits, i) != 0xffffffffu;
                     if (!is_hit) {
                         const float4* qp = wf_path_rec(queue_in, W.cap, i);
                         const float4 q2 = qp[0], q3 = qp[1];
@@ -1419,7 +1434,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
                 __shared__ uint32_t agg_sorted[WF_SHADE_THREADS];
                 uint32_t key = 8u, rank = 0u;
                 if (threadIdx.x < take) {
-                    const uint32_t prim = hits[mine].x & 0x0fffffffu;
+                    const uint32_t prim = wf_hit_word(hits, mine) & 0x0fffffffu;
                     key = __float_as_uint(S.prim_attr[(size_t)prim * 4 + 3].w) & 7u;
                 }
 #pragma unroll
