@@ -11,7 +11,7 @@ from pathlib import Path
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-PTO_BRUTE_FORCE, PTO_BVH = 0, 1
+PTO_BRUTE_FORCE, PTO_BVH, PTO_NO_SCENE_SLAB = 0, 1, 2
 _lib = None
 
 

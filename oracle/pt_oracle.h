@@ -6,11 +6,12 @@
  * only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as
  * the checker / CPU baseline.  Nothing in the product path may call it.
  *
- * Parity pin: this code reproduces six of the reference's seven golden
- * SHA-1 image hashes bit-exactly (src/main.rs:104,112,120,128,136,144) and all
+ * Parity pin: this code reproduces ALL SEVEN of the reference's golden SHA-1
+ * image hashes bit-exactly (src/main.rs:104,112,120,128,136,144,162) and all
  * 6 024 Möller–Trumbore vectors (tests/moller_trumbore/{hit,miss}_tests.yml); see
- * tests/test_oracle_golden.py.  white_furnace_direct (src/main.rs:162) is not
- * reproducible — that one hash is "parity unpinned".
+ * tests/test_oracle_golden.py.  The seventh (white_furnace_direct, which SURVEY
+ * §0.3 could not reproduce) pins the f32 slab test of the kdtree-ray candidate
+ * filter: see kdtree_ray_slab in pt_oracle.cpp and DESIGN §6.
  */
 #ifndef PT_ORACLE_H
 #define PT_ORACLE_H
@@ -26,12 +27,20 @@ typedef struct pto_scene pto_scene;
 /* mode bits for pto_scene_create */
 enum {
     PTO_BRUTE_FORCE = 0, /* test every primitive of every model (literal)      */
-    PTO_BVH = 1          /* AABB-tree candidate filter standing in for
-                            kdtree-ray (result-neutral)           */
+    PTO_BVH = 1,         /* AABB-tree with padded boxes in front of the
+                            primitive tests (result-neutral accelerator)       */
+    PTO_NO_SCENE_SLAB = 2 /* study switch: WITHOUT kdtree-ray's f32 slab test
+                            against the scene's bounding box (the behaviour
+                            SURVEY §0.2 assumed; it misses the 7th golden by
+                            2 samples, see kdtree_ray_slab in pt_oracle.cpp)   */
 };
 
 int pto_scene_create(const pt_scene_desc* desc, int mode, pto_scene** out);
 void pto_scene_destroy(pto_scene* s);
+
+/* Study hook (white_furnace_direct investigation): primitives with mask[p] != 0 are never returned by the
+ * candidate filter.  n = primitive count, or 0 to clear. */
+int pto_scene_hide_prims(pto_scene* s, const uint8_t* mask, uint64_t n);
 
 typedef struct pto_stats {
     uint64_t samples;
