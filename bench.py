@@ -352,7 +352,7 @@ def main():
                                    f"{args.scene_flags}), {args.width}x{args.height}, {args.spp} spp, "
                                    f"{args.bounces} bounces, COOK_TORRANCE, {args.tonemap}",
                        "parallelism": f"{world} x tile-sharded (32x32 interleaved)" + (", RCCL all-gather of u8 framebuffer" if world > 1 else ""),
-                       "kd": {k: info[k] for k in ("n_prims", "n_kd_nodes", "n_kd_leaves", "n_leaf_refs", "kd_depth")},
+                       "kd": {k: info[k] for k in ("n_prims", "n_kd_nodes", "n_kd_leaves", "n_leaf_refs", "kd_depth", "n_edge_prims")},
                        "origin_grids": {k: info[k] for k in ("cam_grid_res", "light_grids", "grid_refs")},
                        "setup_seconds": round(setup_s, 2), "kd_build_seconds": round(info["kd_build_seconds"], 2),
                        "grid_build_seconds": round(info["grid_build_seconds"], 2)},

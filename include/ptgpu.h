@@ -327,7 +327,8 @@ typedef struct pt_scene_info {
     uint32_t light_grids;     /* lights whose shadow rays use a grid (all or none)    */
     uint64_t grid_refs;       /* list entries of all grids                            */
     float grid_build_seconds;
-    uint32_t _pad;
+    uint32_t n_edge_prims;    /* primitives close to an edge of the scene's bounding box: a hit on one of them is
+                                 subject to kdtree-ray's f32 slab test (csrc/pt_integrator.h scene_slab)        */
 } pt_scene_info;
 int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out);
 

@@ -118,7 +118,7 @@ class SceneInfo(C.Structure):
                 ("n_leaf_refs", C.c_uint64), ("kd_depth", C.c_uint32), ("has_translucent", C.c_uint32),
                 ("kd_build_seconds", C.c_float), ("upload_seconds", C.c_float), ("device_bytes", C.c_uint64),
                 ("cam_grid_res", C.c_uint32), ("light_grids", C.c_uint32), ("grid_refs", C.c_uint64),
-                ("grid_build_seconds", C.c_float), ("_pad", C.c_uint32)]
+                ("grid_build_seconds", C.c_float), ("n_edge_prims", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -9,10 +9,12 @@
 //               128-B line); the host builder's DFS array (include/pthost.h) is permuted on upload
 //   leaf_prims  48 B / leaf reference, stored leaf after leaf so a leaf's
 //               primitives are one contiguous, 16-B aligned run:
-//                 q0 = (v0.x, v0.y, v0.z, bits(prim_id | kind<<31))
+//                 q0 = (v0.x, v0.y, v0.z, bits(prim_id | kind<<31 | edge<<30))
 //                 q1 = (e1.x, e1.y, e1.z, e2.x)      e1 = v1 - v0 (f32, as
 //                 q2 = (e2.y, e2.z, 0, 0)            triangle.rs:43-44 computes it)
 //               spheres: q0 = (c.x, c.y, c.z, bits(prim | 1<<31)), q1.x = radius
+//               edge: the primitive comes close to an edge of the scene's bounding box, a cast that ends on it is
+//               subject to kdtree-ray's slab test (scene_slab, pt_integrator.h)
 //   prim_attr   64 B / primitive, indexed by global primitive id (shading only):
 //                 a0 = (n0.xyz, uv0.x) a1 = (n1.xyz, uv0.y) a2 = (n2.xyz, uv1.x)
 //                 a3 = (uv1.y, uv2.x, uv2.y, bits(model))
@@ -29,6 +31,8 @@
 #include "ptgpu.h"
 
 #define PT_PRIM_SPHERE 0x80000000u
+#define PT_PRIM_EDGE 0x40000000u     // the primitive comes close to an edge of the scene's bounding box (scene_slab)
+#define PT_PRIM_INDEX(pid) ((pid) & 0x3fffffffu)
 #define PT_KD_STACK 64
 
 struct DevLight {
@@ -73,6 +77,8 @@ struct DevScene {
     uint32_t has_translucent;
     float bounds_min[3];
     float bounds_max[3];
+    float slab_min[3];       // the EXACT bounding box of the scene (union of Model::bound(), model.rs:76-86): the box of
+    float slab_max[3];       // kdtree-ray's slab test (scene_slab, pt_integrator.h)
     // camera (internal/camera.rs:36-48): columns of the transform, tan(fov/2) from host tanf
     float cam_c0[3], cam_c1[3], cam_c2[3], cam_c3[3];
     float tan_half_fov;

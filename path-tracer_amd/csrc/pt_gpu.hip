@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t* __restrict__ ga
 
 // ------------------------------------------------------------------ test-hook kernels
 __device__ __forceinline__ void store_hit(pt_hit& o, const RawHit& h) {
-    o.prim = (int32_t)(h.pid & ~PT_PRIM_SPHERE);
+    o.prim = (int32_t)PT_PRIM_INDEX(h.pid);
     o.flags = (int32_t)h.flags;
     o.dist = h.key;
     o.u = (h.flags & 2u) ? 0.f : h.u;
@@ -616,6 +616,67 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
             pos[prim * 3 + 2] = make_float4(0, 0, 0, 0);
             ++prim;
         }
+    }
+    // ---- kdtree-ray's slab test (scene_slab, pt_integrator.h): the exact bounding box of the scene - the union of
+    // Model::bound() (model.rs:76-86: the positions' bounds for a mesh, centre -+ radius for a sphere) - and the mark
+    // on every primitive that comes close to one of its EDGES.  Only a ray that clips an edge of the box within the
+    // rounding of the test (~1e-7 of its length) can fail it while hitting something, and whatever it hits then lies
+    // within that distance (plus the slop of the intersection tests) of the edge.  delta = 1e-4 x (the largest distance a
+    // ray of this scene can cover: the box diagonal, or from the camera to its far corner) is a hundred times that; a
+    // primitive within delta of an edge has its own bounds within delta of the two faces that meet there.
+    {
+        DevScene& D = P.dev;
+        for (int a = 0; a < 3; ++a) {
+            D.slab_min[a] = INFINITY;
+            D.slab_max[a] = -INFINITY;
+        }
+        std::vector<float> pmn(n_prims * 3), pmx(n_prims * 3);
+        uint64_t q = 0;
+        for (uint32_t m = 0; m < d.n_models; ++m) {
+            const pt_model& mo = d.models[m];
+            const uint32_t cnt = mo.kind == PT_MODEL_MESH ? mo.tri_count : 1u;
+            for (uint32_t t = 0; t < cnt; ++t, ++q) {
+                for (int a = 0; a < 3; ++a) {
+                    float lo, hi;
+                    if (mo.kind == PT_MODEL_MESH) {
+                        const float* v = d.triangles + (size_t)(mo.tri_first + t) * 24;
+                        lo = fminf(fminf(v[a], v[8 + a]), v[16 + a]);
+                        hi = fmaxf(fmaxf(v[a], v[8 + a]), v[16 + a]);
+                    } else {
+                        lo = mo.center[a] - mo.radius;
+                        hi = mo.center[a] + mo.radius;
+                    }
+                    pmn[q * 3 + a] = lo;
+                    pmx[q * 3 + a] = hi;
+                    D.slab_min[a] = fminf(D.slab_min[a], lo);
+                    D.slab_max[a] = fmaxf(D.slab_max[a], hi);
+                }
+            }
+        }
+        double diag2 = 0, cam2 = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double w = (double)D.slab_max[a] - D.slab_min[a], c = d.camera.transform[12 + a];
+            const double far = std::max(std::fabs(c - D.slab_min[a]), std::fabs(c - D.slab_max[a]));
+            diag2 += w * w;
+            cam2 += far * far;
+        }
+        const double reach = std::sqrt(std::max(diag2, cam2));
+        const float delta = std::isfinite(reach) ? (float)(1e-4 * reach) : INFINITY;
+        if (n_prims >= (1ull << 28)) fail(PT_ERR_UNSUPPORTED, "more than 2^28 primitives");   // (pack_hit's index bits)
+        uint64_t marked = 0;
+        for (uint64_t k = 0; k < n_prims; ++k) {
+            int near_faces = 0;
+            for (int a = 0; a < 3; ++a)
+                if (!(pmn[k * 3 + a] > D.slab_min[a] + delta) || !(pmx[k * 3 + a] < D.slab_max[a] - delta)) ++near_faces;
+            if (near_faces >= 2) {
+                uint32_t w;
+                memcpy(&w, &pos[k * 3].w, 4);
+                w |= PT_PRIM_EDGE;
+                memcpy(&pos[k * 3].w, &w, 4);
+                ++marked;
+            }
+        }
+        P.info.n_edge_prims = (uint32_t)std::min<uint64_t>(marked, 0xffffffffu);
     }
     // leaf records in leaf-reference order
     P.leaf.resize(kd.n_refs * 3);

@@ -48,7 +48,7 @@ PT_D void og_test_closest(f3 o, f3 d, float4 q0, float4 q1, float4 q2, float t_p
         float dist, u, v;
         bool bf;
         if (!isect_triangle(o, d, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), dist, u, v, bf)) return;
-        const uint32_t ord = pid * 2u;
+        const uint32_t ord = PT_PRIM_INDEX(pid) * 2u;
         if (key_less(t_prev, ord_prev, dist, ord) && key_less(dist, ord, best.key, best.ord)) {
             best.key = dist;
             best.ord = ord;
@@ -62,7 +62,7 @@ PT_D void og_test_closest(f3 o, f3 d, float4 q0, float4 q1, float4 q2, float t_p
         bool ex[2];
         const int nh = isect_sphere(o, d, mk3(q0.x, q0.y, q0.z), q1.x, t, key, ex);
         for (int k = 0; k < nh; ++k) {
-            const uint32_t ord = (pid & ~PT_PRIM_SPHERE) * 2u + (ex[k] ? 1u : 0u);
+            const uint32_t ord = PT_PRIM_INDEX(pid) * 2u + (ex[k] ? 1u : 0u);
             if (key[k] == key[k] && key_less(t_prev, ord_prev, key[k], ord) && key_less(key[k], ord, best.key, best.ord)) {
                 best.key = key[k];
                 best.ord = ord;
@@ -98,6 +98,8 @@ PT_D bool og_next_hit(const DevScene& S, const DevGrid& G, uint32_t cell, f3 o, 
         const float4* pp = S.prim_pos + (size_t)(r.x & ~PT_PRIM_SPHERE) * 3;
         og_test_closest<COUNT>(o, d, pp[0], pp[1], pp[2], t_prev, ord_prev, best, lc);
     }
+    // kdtree-ray's box test (scene_slab): a ray it rejects has no hits at all
+    if (best.pid != 0xffffffffu && !hit_passes_slab(S, best.pid, o, d)) best.pid = 0xffffffffu;
     return best.pid != 0xffffffffu;
 }
 
@@ -105,7 +107,7 @@ PT_D bool og_next_hit(const DevScene& S, const DevGrid& G, uint32_t cell, f3 o, 
 // opacity exactly 1); otherwise (directional light, mod.rs:291-297) any hit at all?  `ldist` is also the scan limit
 // of the list (point light: distance surface - light; directional: minus the depth of the ray's origin).
 template <bool COUNT, bool RANGED>
-PT_D bool og_blocked(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, f3 sd, f3 pos, float ldist, LocalCtr& lc) {
+PT_D uint32_t og_blocker(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, f3 sd, f3 pos, float ldist, LocalCtr& lc) {
     const uint32_t first = G.cell_off[cell], last = G.cell_off[cell + 1u];
     const uint32_t n_all = G.n_global + (last - first);
     for (uint32_t j = 0; j < n_all; ++j) {
@@ -121,7 +123,7 @@ PT_D bool og_blocked(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, 
             if (!isect_triangle(so, sd, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), t, u, v, bf))
                 continue;
             if (RANGED && mag3((so + sd * t) - pos) > ldist) continue;
-            return true;
+            return __float_as_uint(q0.w);
         } else {
             float t[2], key[2];
             bool ex[2];
@@ -129,11 +131,18 @@ PT_D bool og_blocked(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, 
             for (int h = 0; h < nh; ++h) {
                 if (!(key[h] == key[h])) continue;
                 if (RANGED && mag3((so + sd * t[h]) - pos) > ldist) continue;
-                return true;
+                return __float_as_uint(q0.w);
             }
         }
     }
-    return false;
+    return 0xffffffffu;
+}
+// (the id word of the first occluder found, 0xffffffff = none; kdtree-ray's box test once, after the scan: a ray the
+// scene box rejects has no hits at all)
+template <bool COUNT, bool RANGED>
+PT_D bool og_blocked(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, f3 sd, f3 pos, float ldist, LocalCtr& lc) {
+    const uint32_t pid = og_blocker<COUNT, RANGED>(S, G, cell, so, sd, pos, ldist, lc);
+    return pid != 0xffffffffu && hit_passes_slab(S, pid, so, sd);
 }
 
 
@@ -192,7 +201,7 @@ PT_D f3 og_light_radiance(const DevScene& S, uint32_t li, f3 pos, f3 gn, f2 uv, 
         const f3 sp = so + sd * ((h.flags & 2u) ? h.u : h.key);
         if (mag3(sp - pos) > ldist) break;
         // the SHADED hit's kind / uv with the occluder's material (mod.rs:324)
-        const uint32_t smodel = __float_as_uint(S.prim_attr[(size_t)(h.pid & ~PT_PRIM_SPHERE) * 4 + 3].w);
+        const uint32_t smodel = __float_as_uint(S.prim_attr[(size_t)PT_PRIM_INDEX(h.pid) * 4 + 3].w);
         rad = rad * (1.f - material_opacity(S, smodel, sphere, uv));
         if (sum3(rad) == 0.f) break;
         t_prev = h.key;

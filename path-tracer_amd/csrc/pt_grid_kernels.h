@@ -90,8 +90,10 @@ PT_D void og_retire(f3 color, uint32_t next_idx, uint32_t out_slot, float4* __re
 // Used for bounces >= 1: there a lean kernel of its own (60 registers, 8 waves per SIMD) next to the 128-register
 // shade kernel beats casting inline (MI355X, config 3, bounce 1: 3.66 + 0.74 ms against 5.98 ms).
 // ---------------------------------------------------------------------------
+// (opaque scenes: held to the 64 registers of 8 waves per SIMD; the rarely taken branch of kdtree-ray's box test would
+// otherwise raise the allocation to 70 and cost a wave)
 template <bool ALPHA, bool COUNT, bool DIRL>
-__global__ __launch_bounds__(256) void k_og_shadow(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
+__global__ __launch_bounds__(256, (!ALPHA && !COUNT && !DIRL) ? 8 : 1) void k_og_shadow(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
                                                    const float4* __restrict__ contrib, float4* __restrict__ queue_next,
                                                    float* __restrict__ staging, uint32_t* __restrict__ offgrid,
                                                    WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {

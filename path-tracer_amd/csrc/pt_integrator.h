@@ -28,7 +28,7 @@ struct LocalCtr {
 struct RawHit {
     float key;       // Hit::get_dist(): the sort key of ray_cast (utils.rs:19)
     uint32_t ord;    // tie order: primitive id * 2 (+1 for a sphere's exit hit)
-    uint32_t pid;    // primitive id | PT_PRIM_SPHERE
+    uint32_t pid;    // primitive id | PT_PRIM_SPHERE | PT_PRIM_EDGE
     float u, v;      // barycentrics; spheres: u = ray parameter t of the hit
     uint32_t flags;  // bit0 backface, bit1 sphere, bit2 sphere exit
 };
@@ -181,6 +181,34 @@ PT_D int isect_sphere(f3 o, f3 d, f3 center, float radius, float t[2], float key
     return 2;
 }
 
+// kdtree-ray's ray / box test against the scene's bounding box (the reference filters every ray_cast through the
+// crate, utils.rs:13; its slab method in f32 - inv = 1 / d, t = (bound - o) * inv, tmin = max of the per-axis minima,
+// tmax = min of the maxima, f32::min / max dropping NaN, hit <=> tmax >= max(tmin, 0) - rejects a ray that clips an
+// EDGE of the box within rounding although a triangle lying in one of the two faces is hit: the reference's golden
+// white_furnace_direct, main.rs:149-165, pins two such camera rays; oracle: kdtree_ray_slab).  Every space of the
+// crate's trees is a sub-box of this box, so what the box rejects no space accepts: the cast has no hits at all.
+// Only a ray whose hits lie within ~1e-6 of its length of a box edge can fail, i.e. only hits on primitives that come
+// that close to an edge: the host marks those (PT_PRIM_EDGE in the record's id word, prep_create) and a cast calls this
+// once, at its end, when its result is a marked primitive - never for a curved mesh in the middle of its box.
+PT_D bool scene_slab(const DevScene& S, f3 o, f3 d) {
+    const float oa[3] = {o.x, o.y, o.z}, da[3] = {d.x, d.y, d.z};
+    float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inv = 1.0f / da[a];
+        const float t1 = (S.slab_min[a] - oa[a]) * inv, t2 = (S.slab_max[a] - oa[a]) * inv;
+        tmin = fmaxf(tmin, fminf(t1, t2));
+        tmax = fminf(tmax, fmaxf(t1, t2));
+    }
+    return tmax >= fmaxf(tmin, 0.f);
+}
+// Does the cast that ended on primitive `pid` survive kdtree-ray's box test?
+#ifdef PT_NO_SCENE_SLAB   // A/B builds only (tools/build_variant.sh): what the test costs
+PT_D bool hit_passes_slab(const DevScene&, uint32_t, f3, f3) { return true; }
+#else
+PT_D bool hit_passes_slab(const DevScene& S, uint32_t pid, f3 o, f3 d) { return !(pid & PT_PRIM_EDGE) || scene_slab(S, o, d); }
+#endif
+
 PT_D bool key_less(float ka, uint32_t oa, float kb, uint32_t ob) { return ka < kb || (ka == kb && oa < ob); }
 
 // The entry of ray_cast()'s sorted list that follows (t_prev, ord_prev); the
@@ -207,7 +235,7 @@ PT_D bool next_hit(const DevScene& S, f3 o, f3 d, float t_prev, uint32_t ord_pre
                 if (!isect_triangle(o, d, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), dist,
                                     u, v, bf))
                     continue;
-                uint32_t ord = pid * 2u;
+                uint32_t ord = PT_PRIM_INDEX(pid) * 2u;
                 if (key_less(t_prev, ord_prev, dist, ord) && key_less(dist, ord, best.key, best.ord)) {
                     best.key = dist;
                     best.ord = ord;
@@ -222,7 +250,7 @@ PT_D bool next_hit(const DevScene& S, f3 o, f3 d, float t_prev, uint32_t ord_pre
                 bool ex[2];
                 int nh = isect_sphere(o, d, mk3(q0.x, q0.y, q0.z), q1.x, t, key, ex);
                 for (int k = 0; k < nh; ++k) {
-                    uint32_t ord = (pid & ~PT_PRIM_SPHERE) * 2u + (ex[k] ? 1u : 0u);
+                    uint32_t ord = PT_PRIM_INDEX(pid) * 2u + (ex[k] ? 1u : 0u);
                     if (key[k] == key[k] && key_less(t_prev, ord_prev, key[k], ord) &&
                         key_less(key[k], ord, best.key, best.ord)) {
                         best.key = key[k];
@@ -238,6 +266,7 @@ PT_D bool next_hit(const DevScene& S, f3 o, f3 d, float t_prev, uint32_t ord_pre
         }
         return false;
     });
+    if (best.pid != 0xffffffffu && !hit_passes_slab(S, best.pid, o, d)) best.pid = 0xffffffffu;   // no hits at all
     return best.pid != 0xffffffffu;
 }
 
@@ -255,7 +284,7 @@ struct Surface {
 };
 
 PT_D void make_surface(const DevScene& S, f3 o, f3 d, const RawHit& h, Surface& s) {
-    uint32_t prim = h.pid & ~PT_PRIM_SPHERE;
+    uint32_t prim = PT_PRIM_INDEX(h.pid);
     const float4* at = S.prim_attr + (size_t)prim * 4;
     float4 a3 = at[3];
     s.model = __float_as_uint(a3.w);
@@ -324,7 +353,7 @@ PT_D float material_opacity(const DevScene& S, uint32_t model, bool kind_sphere,
 // rays, mod.rs:289-297).  Only a material with an opacity TEXTURE needs the hit's uv - i.e. the surface record
 // with its three attribute fetches and the interpolation; everywhere else the opacity is the material's factor.
 PT_D float hit_opacity(const DevScene& S, f3 o, f3 d, const RawHit& h) {
-    const uint32_t model = __float_as_uint(S.prim_attr[(size_t)(h.pid & ~PT_PRIM_SPHERE) * 4 + 3].w);
+    const uint32_t model = __float_as_uint(S.prim_attr[(size_t)PT_PRIM_INDEX(h.pid) * 4 + 3].w);
     const pt_material& m = S.materials[model];
     if ((h.flags & 2u) || m.tex_opacity < 0) return m.opacity;   // spheres ignore textures (MaterialSample::simple)
     Surface sf;
@@ -483,6 +512,7 @@ PT_D void light_radiance(const DevScene& S, const DevLight& L, const Surface& hi
         // Every opacity is exactly 1: the first list entry that passes the range
         // test zeroes the colour, so "any hit in range" decides.
         bool blocked = false;
+        uint32_t blocker = 0u;
         float dlen = mag3(sd);
         float key_scale = dlen < 1.0f ? dlen : 1.0f;
         // hits farther than the light cannot pass the range test (|so + sd*t - pos| > dist)
@@ -501,6 +531,7 @@ PT_D void light_radiance(const DevScene& S, const DevLight& L, const Surface& hi
                         continue;
                     if (point && mag3((so + sd * t) - hit.pos) > dist) continue;
                     blocked = true;
+                    blocker = pid;
                     return true;
                 } else {
                     float t[2], key[2];
@@ -510,12 +541,14 @@ PT_D void light_radiance(const DevScene& S, const DevLight& L, const Surface& hi
                         if (!(key[k] == key[k])) continue;
                         if (point && mag3((so + sd * t[k]) - hit.pos) > dist) continue;
                         blocked = true;
+                        blocker = pid;
                         return true;
                     }
                 }
             }
             return false;
         });
+        if (blocked && !hit_passes_slab(S, blocker, so, sd)) blocked = false;   // (a ray the box rejects has no hits at all)
         radiance = blocked ? color * 0.0f : color;
         return;
     }
@@ -533,7 +566,7 @@ PT_D void light_radiance(const DevScene& S, const DevLight& L, const Surface& hi
             f3 sp = so + sd * ((h.flags & 2u) ? h.u : h.key);
             if (mag3(sp - hit.pos) > dist) break;
             // the SHADED hit's kind / uv with the occluder's material (mod.rs:324)
-            uint32_t smodel = __float_as_uint(S.prim_attr[(size_t)(h.pid & ~PT_PRIM_SPHERE) * 4 + 3].w);
+            uint32_t smodel = __float_as_uint(S.prim_attr[(size_t)PT_PRIM_INDEX(h.pid) * 4 + 3].w);
             opacity = material_opacity(S, smodel, hit.sphere, hit.uv);
         } else {
             Surface sh;

@@ -441,7 +441,7 @@ PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_pre
             if (!isect_triangle(T.o, T.d, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), dist, u,
                                 v, bf))
                 continue;
-            uint32_t ord = pid * 2u;
+            uint32_t ord = PT_PRIM_INDEX(pid) * 2u;
             if (key_less(t_prev, ord_prev, dist, ord) && key_less(dist, ord, best.key, best.ord)) {
                 best.key = dist;
                 best.ord = ord;
@@ -455,7 +455,7 @@ PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_pre
             bool ex[2];
             int nh = isect_sphere(T.o, T.d, mk3(q0.x, q0.y, q0.z), q1.x, t, key, ex);
             for (int k = 0; k < nh; ++k) {
-                uint32_t ord = (pid & ~PT_PRIM_SPHERE) * 2u + (ex[k] ? 1u : 0u);
+                uint32_t ord = PT_PRIM_INDEX(pid) * 2u + (ex[k] ? 1u : 0u);
                 if (key[k] == key[k] && key_less(t_prev, ord_prev, key[k], ord) && key_less(key[k], ord, best.key, best.ord)) {
                     best.key = key[k];
                     best.ord = ord;
@@ -621,6 +621,10 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
     auto complete = [&]() {
         lstate = WF_LANE_WALK;
         bool hit = best.pid != 0xffffffffu;
+        if (hit && !hit_passes_slab(S, best.pid, T.o, T.d)) {   // kdtree-ray's box test: no hits at all
+            hit = false;
+            have_kept = false;
+        }
         bool finished = true;
         if (ALPHA && hit) {
             float opacity = hit_opacity(S, T.o, T.d, best);
@@ -1039,7 +1043,8 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
         const unsigned long long winners = __ballot(found) & group_mask;
         if (e < n) {
             if (winners) {
-                if (lane == (uint32_t)__ffsll((long long)winners) - 1u) wf_store_hit(hits, W.cap, idx, best, true);
+                if (lane == (uint32_t)__ffsll((long long)winners) - 1u)
+                    wf_store_hit(hits, W.cap, idx, best, hit_passes_slab(S, best.pid, T.o, T.d));
             } else if (part == 0u) {
                 wf_store_hit(hits, W.cap, idx, best, false);
             }
@@ -1588,6 +1593,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
         if (ALPHA) {
             // best = next entry of the sorted list: attenuate, then look for the following one
             bool more = best.pid != 0xffffffffu;
+            if (more && !hit_passes_slab(S, best.pid, T.o, T.d)) more = false;   // kdtree-ray's box test
             if (more) {
                 float opacity = 0.f;
                 if (point) {
@@ -1596,7 +1602,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
                         more = false;
                     } else {
                         // the SHADED hit's kind / uv with the occluder's material (mod.rs:324)
-                        uint32_t smodel = __float_as_uint(S.prim_attr[(size_t)(best.pid & ~PT_PRIM_SPHERE) * 4 + 3].w);
+                        uint32_t smodel = __float_as_uint(S.prim_attr[(size_t)PT_PRIM_INDEX(best.pid) * 4 + 3].w);
                         opacity = material_opacity(S, smodel, sphere, uv);
                     }
                 } else {
@@ -1671,6 +1677,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
                 // every opacity is exactly 1: any hit inside the light's range blocks it
                 const float4* lp = S.leaf_prims + (size_t)T.leaf.x * 3;
                 uint32_t np = T.leaf.y >> 2;
+                uint32_t blocker = 0u;
                 for (uint32_t i = 0; i < np && !blocked; ++i) {
                     float4 q0, q1, q2;
                     load_prim_record(lp + 3 * i, q0, q1, q2);
@@ -1684,6 +1691,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
                             continue;
                         if (point && mag3((T.o + T.d * t) - pos) > ldist) continue;
                         blocked = true;
+                        blocker = pid;
                     } else {
                         float t[2], key[2];
                         bool ex[2];
@@ -1692,10 +1700,14 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
                             if (!(key[k] == key[k])) continue;
                             if (point && mag3((T.o + T.d * t[k]) - pos) > ldist) continue;
                             blocked = true;
+                            blocker = pid;
                         }
                     }
                 }
-                lstate = (blocked || !trav_pop(T, st, limit)) ? WF_LANE_DONE : WF_LANE_WALK;
+                // kdtree-ray's box test: a ray the scene box rejects has no hits at all
+                const bool rejected = blocked && !hit_passes_slab(S, blocker, T.o, T.d);
+                if (rejected) blocked = false;
+                lstate = (blocked || rejected || !trav_pop(T, st, limit)) ? WF_LANE_DONE : WF_LANE_WALK;
             } else {
                 leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc, mailbox);
                 lstate = trav_pop(T, st, best.key) ? WF_LANE_WALK : WF_LANE_DONE;
