@@ -149,6 +149,9 @@ int pth_origin_grid_build(const pt_scene_desc* desc, const float origin[3], uint
 /* The same for rays that all have `direction` (not necessarily unit: the shadow rays of a directional light,
  * src/renderer/mod.rs:283-299, which run along -light.direction with no distance limit). */
 int pth_ortho_grid_build(const pt_scene_desc* desc, const float direction[3], uint32_t res, pth_origin_grid* out);
+/* The resolution the builders choose for res == 0 (4 sqrt(n) cells per face edge, a power of two in 32 ... 8192; PT_OG_RES
+ * overrides): the caller budgets the memory of all grids of a scene with it (pt_scene_create, PT_OG_BUDGET_GIB). */
+uint32_t pth_origin_grid_auto_resolution(uint64_t n_prims);
 void pth_origin_grid_free(pth_origin_grid* g);
 
 const char* pth_last_error(void);

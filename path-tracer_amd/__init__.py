@@ -169,7 +169,8 @@ _gpu = None
 HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_scene_generate_ps5",
                 "pth_scene_save_isf", "pth_convert_gltf", "pth_profile_load", "pth_profile_parse", "pth_png_read",
                 "pth_png_decode", "pth_png_write_rgb8", "pth_free", "pth_prim_count", "pth_kd_build",
-                "pth_kd_free", "pth_origin_grid_build", "pth_ortho_grid_build", "pth_origin_grid_free", "pth_last_error"]
+                "pth_kd_free", "pth_origin_grid_build", "pth_ortho_grid_build", "pth_origin_grid_auto_resolution", "pth_origin_grid_free",
+                "pth_last_error"]
 # Every symbol include/ptgpu.h declares.
 GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_prep_create", "pt_prep_destroy", "pt_scene_create_from_prep",
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_gather_tiles", "pt_render_gathered", "pt_local_pixel_count", "pt_local_pixel_map",

@@ -779,32 +779,56 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
         for (int k = 0; k < 3; ++k)
             for (int r = 0; r < 3; ++r) fro += (double)M[4 * k + r] * M[4 * k + r];
         fro = std::sqrt(fro);
-        if (grids_on && n_prims > 0 && fro > 0 && fro < 64.0) {
+        // Byte budget over ALL grids of the scene (PT_OG_BUDGET_GIB, default 48 of the 288 GB): the grids are an optional
+        // accelerator in front of the KD-tree, one per camera and per light, 6 res^2 cells of 4 B plus ~1.5x that in list
+        // entries each (8192^2: ~4 GB a grid) - a scene with many lights must not run the host or the device out of
+        // memory over them.  The resolution is halved (down to 512) until the estimate fits; if it still does not, or
+        // the grids as built exceed the budget, the lights go without (their shadow rays take the KD-tree).
+        static const double budget = [] {
+            const char* e = getenv("PT_OG_BUDGET_GIB");
+            const double g = e && *e ? atof(e) : 48.0;
+            return (g > 0 ? g : 48.0) * 1073741824.0;
+        }();
+        auto estimate = [](uint32_t r) { return 6.0 * r * r * 4.0 * 2.5; };
+        uint32_t res = pth_origin_grid_auto_resolution(n_prims);
+        const double n_grids = 1.0 + d.n_lights;
+        while (res > 512u && estimate(res) * n_grids > budget) res >>= 1;
+        bool lights_fit = estimate(res) * n_grids <= budget;
+        const uint32_t light_res = res;
+        if (!lights_fit) {   // the camera grid alone, at the resolution it is worth having
+            res = pth_origin_grid_auto_resolution(n_prims);
+            while (res > 512u && estimate(res) > budget) res >>= 1;
+        }
+        double grid_bytes = 0;
+        if (grids_on && n_prims > 0 && fro > 0 && fro < 64.0 && estimate(res) <= budget) {
             P.cam_grid = std::make_unique<pt_prep::Grid>();
-            if (pth_origin_grid_build(&d, M + 12, 0, 0.f, (float)(fro * 1.001), &P.cam_grid->g) != PT_OK)
+            if (pth_origin_grid_build(&d, M + 12, res, 0.f, (float)(fro * 1.001), &P.cam_grid->g) != PT_OK)
                 fail(PT_ERR_INVALID, "origin grid (camera): %s", pth_last_error());
             if (P.cam_grid->g.enabled) {
                 P.info.cam_grid_res = P.cam_grid->g.res;
                 P.info.grid_refs += P.cam_grid->g.n_refs;
+                grid_bytes += 4.0 * P.cam_grid->g.n_cells + 8.0 * P.cam_grid->g.n_refs;
             }
         }
         // lights: the shadow queue is consumed by ONE kernel, so the grids serve the shadow rays only when EVERY
         // light has one - a cube map around a point light, an orthographic grid along a directional light.  A
         // point light's shadow ray starts n * 1e-5 off the line through the light (mod.rs:319): the grids' margin
         // covers |n| <= 1.5, longer normals take the KD-tree per surface.
-        bool all = grids_on && n_prims > 0;   // (no lights at all: vacuously)
+        bool all = grids_on && n_prims > 0 && lights_fit;   // (no lights at all: vacuously)
         const float max_normal = 1.5f;
         for (uint32_t i = 0; i < d.n_lights && all; ++i) {
             P.light_grids.push_back(std::make_unique<pt_prep::Grid>());
             int rc;
             if (d.lights[i].kind == PT_LIGHT_POINT) {
-                rc = pth_origin_grid_build(&d, d.lights[i].vec, 0, 1.05e-5f * max_normal, 1.001f, &P.light_grids.back()->g);
+                rc = pth_origin_grid_build(&d, d.lights[i].vec, light_res, 1.05e-5f * max_normal, 1.001f, &P.light_grids.back()->g);
             } else {   // the shadow rays run along -direction (mod.rs:291), as it is
                 const float sd[3] = {-1.f * d.lights[i].vec[0], -1.f * d.lights[i].vec[1], -1.f * d.lights[i].vec[2]};
-                rc = pth_ortho_grid_build(&d, sd, 0, &P.light_grids.back()->g);
+                rc = pth_ortho_grid_build(&d, sd, light_res, &P.light_grids.back()->g);
             }
             if (rc != PT_OK) fail(PT_ERR_INVALID, "origin grid (light %u): %s", i, pth_last_error());
             if (!P.light_grids.back()->g.enabled) all = false;
+            grid_bytes += 4.0 * P.light_grids.back()->g.n_cells + 8.0 * P.light_grids.back()->g.n_refs;
+            if (grid_bytes > budget) all = false;   // (the lists came out longer than estimated)
         }
         if (!all) P.light_grids.clear();
         for (auto& g : P.light_grids) P.info.grid_refs += g->g.n_refs;
@@ -860,13 +884,45 @@ void scene_upload(const pt_prep& P, int device, pt_scene& s) {
         out.v0 = g.v0;
         out.cells_per_unit = g.cells_per_unit;
     };
+    // The grids are optional: a device that cannot hold them renders through the KD-tree (the light grids go first,
+    // then the camera grid) instead of failing the scene.
+    auto drop_allocations_from = [&](size_t mark, uint64_t bytes_mark) {
+        for (size_t k = mark; k < s.allocations.size(); ++k) (void)hipFree(s.allocations[k]);
+        s.allocations.resize(mark);
+        s.info.device_bytes = bytes_mark;
+        (void)hipGetLastError();
+    };
     memset(&D.cam_grid, 0, sizeof D.cam_grid);
-    if (P.cam_grid) upload_grid(P.cam_grid->g, D.cam_grid);
+    if (P.cam_grid) {
+        const size_t mark = s.allocations.size();
+        const uint64_t bytes_mark = s.info.device_bytes;
+        try {
+            upload_grid(P.cam_grid->g, D.cam_grid);
+        } catch (const GpuError&) {
+            drop_allocations_from(mark, bytes_mark);
+            memset(&D.cam_grid, 0, sizeof D.cam_grid);
+            s.info.grid_refs -= P.cam_grid->g.enabled ? P.cam_grid->g.n_refs : 0;
+            s.info.cam_grid_res = 0;
+        }
+    }
     std::vector<DevGrid> lgrids(P.lights.size());
     for (auto& g : lgrids) memset(&g, 0, sizeof g);
-    for (size_t i = 0; i < P.light_grids.size(); ++i) {
-        upload_grid(P.light_grids[i]->g, lgrids[i]);
-        if (P.light_grids[i]->g.kind != 0) s.ortho_light_grids = true;
+    {
+        const size_t mark = s.allocations.size();
+        const uint64_t bytes_mark = s.info.device_bytes;
+        try {
+            for (size_t i = 0; i < P.light_grids.size(); ++i) {
+                upload_grid(P.light_grids[i]->g, lgrids[i]);
+                if (P.light_grids[i]->g.kind != 0) s.ortho_light_grids = true;
+            }
+        } catch (const GpuError&) {
+            drop_allocations_from(mark, bytes_mark);
+            for (auto& g : lgrids) memset(&g, 0, sizeof g);
+            for (auto& g : P.light_grids) s.info.grid_refs -= g->g.n_refs;
+            s.ortho_light_grids = false;
+            D.all_lights_gridded = 0u;
+            s.info.light_grids = 0;
+        }
     }
     D.light_grids = s.upload(lgrids.data(), lgrids.size());
     s.info.upload_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_up).count();

@@ -304,6 +304,19 @@ const JVal& element(const JVal& root, const char* array, int64_t i) {
     return a->arr[(size_t)i];
 }
 
+// A JSON number that must be a byte offset / length / count: finite, integral, in [0, 2^53) - the range in which a
+// double holds integers exactly; anything else is a malformed file, not a value to cast (casting a negative or huge double
+// to size_t is undefined behaviour, and sums of unchecked values wrap).
+size_t size_field(const JVal& obj, const char* key, size_t dflt, const char* what) {
+    if (!obj.has(key)) return dflt;
+    const double d = obj.number(key, 0);
+    if (!(d >= 0.0) || !(d < 9007199254740992.0) || d != std::floor(d))
+        fail(PT_ERR_PARSE, "glTF: %s.%s = %g is not a valid size", what, key, d);
+    return (size_t)d;
+}
+// off + len <= size, without overflow
+bool range_fits(size_t off, size_t len, size_t size) { return off <= size && len <= size - off; }
+
 // One accessor, converted to f32 components (normalised integers are scaled) or to u32 indices.
 struct View {
     const uint8_t* data;
@@ -319,7 +332,7 @@ View accessor_view(const Document& doc, int64_t index) {
     v.n_comp = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : 0;
     if (!v.n_comp) fail(PT_ERR_UNSUPPORTED, "glTF: accessor type %s is not supported", type.c_str());
     v.comp_type = (int)acc.number("componentType", 0);
-    v.count = (size_t)acc.number("count", 0);
+    v.count = size_field(acc, "count", 0, "accessor");
     v.normalized = acc.get("normalized") && acc.get("normalized")->b;
     size_t comp_size = v.comp_type == 5126 || v.comp_type == 5125 ? 4 : (v.comp_type == 5122 || v.comp_type == 5123) ? 2
                      : (v.comp_type == 5120 || v.comp_type == 5121) ? 1 : 0;
@@ -328,11 +341,17 @@ View accessor_view(const Document& doc, int64_t index) {
     int64_t bi = bv.index("buffer");
     if (bi < 0 || (size_t)bi >= doc.buffers.size()) fail(PT_ERR_PARSE, "glTF: bufferView without a buffer");
     const std::vector<uint8_t>& buf = doc.buffers[(size_t)bi];
-    size_t off = (size_t)bv.number("byteOffset", 0) + (size_t)acc.number("byteOffset", 0);
-    v.stride = (size_t)bv.number("byteStride", 0);
-    if (!v.stride) v.stride = comp_size * v.n_comp;
-    if (v.count && off + (v.count - 1) * v.stride + comp_size * v.n_comp > buf.size())
-        fail(PT_ERR_PARSE, "glTF: accessor %lld reaches beyond its buffer", (long long)index);
+    const size_t view_off = size_field(bv, "byteOffset", 0, "bufferView"), acc_off = size_field(acc, "byteOffset", 0, "accessor");
+    const size_t elem = comp_size * v.n_comp;
+    v.stride = size_field(bv, "byteStride", 0, "bufferView");
+    if (!v.stride) v.stride = elem;
+    if (v.stride < elem) fail(PT_ERR_PARSE, "glTF: accessor %lld: byteStride %zu is smaller than its %zu-byte elements",
+                              (long long)index, v.stride, elem);
+    // view_off + acc_off + (count - 1) * stride + elem <= buf.size(), every step checked
+    bool fits = range_fits(view_off, acc_off, buf.size());
+    const size_t off = fits ? view_off + acc_off : 0;
+    if (fits && v.count) fits = range_fits(off, elem, buf.size()) && (v.count - 1) <= (buf.size() - off - elem) / v.stride;
+    if (!fits) fail(PT_ERR_PARSE, "glTF: accessor %lld reaches beyond its buffer", (long long)index);
     v.data = buf.data() + off;
     return v;
 }
@@ -406,8 +425,8 @@ struct Converter {
             const JVal& bv = element(doc.root, "bufferViews", img.index("bufferView"));
             int64_t bi = bv.index("buffer");
             if (bi < 0 || (size_t)bi >= doc.buffers.size()) fail(PT_ERR_PARSE, "glTF: image bufferView without a buffer");
-            size_t off = (size_t)bv.number("byteOffset", 0), len = (size_t)bv.number("byteLength", 0);
-            if (off + len > doc.buffers[(size_t)bi].size()) fail(PT_ERR_PARSE, "glTF: image reaches beyond its buffer");
+            const size_t off = size_field(bv, "byteOffset", 0, "bufferView"), len = size_field(bv, "byteLength", 0, "bufferView");
+            if (!range_fits(off, len, doc.buffers[(size_t)bi].size())) fail(PT_ERR_PARSE, "glTF: image reaches beyond its buffer");
             bytes.assign(doc.buffers[(size_t)bi].begin() + off, doc.buffers[(size_t)bi].begin() + off + len);
         }
         if (bytes.size() >= 3 && bytes[0] == 0xff && bytes[1] == 0xd8)

@@ -680,6 +680,8 @@ int pth_origin_grid_build(const pt_scene_desc* desc, const float origin[3], uint
     });
 }
 
+uint32_t pth_origin_grid_auto_resolution(uint64_t n_prims) { return pth::auto_resolution(n_prims); }
+
 int pth_ortho_grid_build(const pt_scene_desc* desc, const float direction[3], uint32_t res, pth_origin_grid* out) {
     return pth::guarded([&] {
         if (!desc || !direction || !out) pth::fail(PT_ERR_INVALID, "pth_ortho_grid_build: null argument");

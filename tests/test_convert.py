@@ -189,6 +189,19 @@ def test_convert_errors(pta, tmp_path):
     attempt(lambda d: d["cameras"][0].update(type="orthographic"), "Orthographic camera not supported")
     attempt(lambda d: d["meshes"][0]["primitives"][0].update(mode=5), "not a triangle list")
     attempt(lambda d: d["accessors"][3].update(count=600), "beyond its buffer")
+    # size arithmetic that would wrap around in size_t: 2^60 elements of stride 16 from offset 4 sum to 0 (mod 2^64)
+    def wrap(d):
+        d["accessors"][0].update(count=2 ** 60, byteOffset=4)
+        d["bufferViews"][d["accessors"][0]["bufferView"]].update(byteStride=16)
+    attempt(wrap, "is not a valid size")
+    def wrap53(d):   # the same below 2^53, where the field itself is a valid integer
+        d["accessors"][0].update(count=2 ** 52, byteOffset=4)
+        d["bufferViews"][d["accessors"][0]["bufferView"]].update(byteStride=4096)
+    attempt(wrap53, "beyond its buffer")
+    attempt(lambda d: d["accessors"][0].update(byteOffset=-8), "is not a valid size")
+    attempt(lambda d: d["accessors"][0].update(count=2.5), "is not a valid size")
+    attempt(lambda d: d["bufferViews"][d["accessors"][0]["bufferView"]].update(byteStride=2), "smaller than its")
+    attempt(lambda d: d["bufferViews"][d["images"][0]["bufferView"]].update(byteOffset=2 ** 52, byteLength=2 ** 52), "image reaches beyond")
     (tmp_path / "file").write_text("x")
     r = subprocess.run([str(CLI), "convert", str(tmp_path / "bad.gltf"), str(tmp_path / "file")], capture_output=True, text=True)
     assert r.returncode == 2 and "is not a directory" in r.stderr                               # gltf.rs:153-155

@@ -30,6 +30,7 @@ for flags in (0, 1):
     g = pta.GpuScene(sc, device=0)
     rgb, acc = g.render(pta.Profile.make(640, 360, 16, 5, "ACES"))
     h.update(rgb.tobytes()); h.update(acc.tobytes())
+print("GRIDS", g.info().cam_grid_res, g.info().light_grids)
 print("SHA", h.hexdigest())
 """
 
@@ -47,7 +48,10 @@ SETTINGS = [
     {"PT_SHADE_BLOCKS_B0": "3", "PT_SHADE_BLOCKS": "1"},   # resident-only shade grids
     {"PT_WF_WALK": "3", "PT_WF_REFILL": "48"},              # odd traversal parameters
     {"PT_TILE_ORDER": "morton"},
+    {"PT_OG_BUDGET_GIB": "0.02"},         # grid memory budget of 20 MB: a coarser camera grid, the light on the KD-tree
+    {"PT_OG_BUDGET_GIB": "0.001"},        # ... of 1 MB: no grid fits
 ]
+EXPECT_GRIDS = {"0.02": "512 0", "0.001": "0 0"}
 
 
 def run_child(extra):
@@ -61,6 +65,11 @@ def run_child(extra):
     assert out.returncode == 0, (extra, out.stderr[-2000:])
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("SHA ")]
     assert len(lines) == 1, (extra, out.stdout[-500:], out.stderr[-500:])
+    grids = [ln for ln in out.stdout.splitlines() if ln.startswith("GRIDS ")][0][6:]
+    if "PT_OG_BUDGET_GIB" in extra:
+        assert grids == EXPECT_GRIDS[extra["PT_OG_BUDGET_GIB"]], (extra, grids)
+    elif extra.get("PT_OG") != "0":
+        assert grids == "1024 1", (extra, grids)
     return lines[0].split()[1]
 
 

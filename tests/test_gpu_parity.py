@@ -462,6 +462,29 @@ def test_textured_generated_scene_is_bit_identical(pta, oracle, flags):
     assert not np.array_equal(plain.render(prof)[0], rgb)
 
 
+@pytest.mark.parametrize("flags", [4, 5, 6])
+def test_closed_room_generated_scene_is_bit_identical(pta, oracle, flags):
+    """The benchmarked closed-room workloads (bench.py --scene-flags 4: four walls and a ceiling around the stand-in,
+    every path shaded at every bounce; 6: plus every texture kind; 5: plus translucent shells) against the oracle:
+    image, f32 accumulation and the exact path-event counters, on all three integrator paths.  The room's walls lie in
+    the faces of the scene's bounding box, so this is also where kdtree-ray's box test (scene_slab) runs all the time."""
+    scene = pta.HostScene.generate_ps5(12000, seed=0, flags=flags)
+    g = pta.GpuScene(scene)
+    assert g.info().n_edge_prims > 0
+    prof = pta.Profile.make(192, 108, 6, 8, "ACES")          # 8 bounces: Russian roulette from bounce 4 on
+    o_rgb, o_acc, st = oracle.OracleScene(scene.desc, oracle.PTO_BVH).render(prof)
+    assert st["numeric_errors"] == 0
+    assert st["segments"] > 2.5 * st["samples"]             # closed: the bounce loop runs on
+    for f in (0, pta.PT_FLAG_NO_GRIDS, pta.PT_FLAG_MEGAKERNEL):
+        rgb, acc = g.render(prof, pta.Opts.make(flags=f))
+        assert np.array_equal(bits(acc), bits(o_acc)) and np.array_equal(rgb, o_rgb), f
+    for f in (0, pta.PT_FLAG_NO_GRIDS):
+        g.render(prof, pta.Opts.make(flags=f | pta.PT_FLAG_COUNTERS))
+        c = g.counters().as_dict()
+        for k in ("samples", "segments", "shadow_rays", "shaded_hits", "rng_draws"):
+            assert c[k] == st[k], (f, k, c[k], st[k])
+
+
 def _write_isf(tmp_path, name, models, lights, background=(0.25, 0.5, 1.0)):
     import json
     cam = {"transform": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 4, 1]], "fov": 0.8, "zfar": 100.0, "znear": 0.1}
@@ -648,6 +671,13 @@ def test_config5_full_size(pta, oracle):
     idx = pta.local_pixel_map(prof, opts)
     r_rgb, r_acc = g.render(prof, opts)
     assert np.array_equal(bits(r_acc), bits(acc[idx])) and np.array_equal(r_rgb, rgb[idx])
+    # the 8192^2 origin grids against the KD-tree (the grids' conservativeness is a rounding ANALYSIS,
+    # host/origin_grid.cpp: this is its widest empirical net) and against the megakernel, one shard each
+    for rank, f in ((5, pta.PT_FLAG_NO_GRIDS), (7, pta.PT_FLAG_MEGAKERNEL)):
+        o2 = pta.Opts.make(shard_rank=rank, shard_count=8, tile_w=32, tile_h=32, flags=f)
+        idx2 = pta.local_pixel_map(prof, o2)
+        k_rgb, k_acc = g.render(prof, o2)
+        assert np.array_equal(bits(k_acc), bits(acc[idx2])) and np.array_equal(k_rgb, rgb[idx2]), f
     # counters on a quarter of the samples of one shard (the instrumented kernels are slower)
     prof_c = pta.Profile.make(3840, 2160, 32, 8, "ACES")
     g.render(prof_c, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS, shard_rank=2, shard_count=8, tile_w=32, tile_h=32))
