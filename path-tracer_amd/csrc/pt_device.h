@@ -65,6 +65,8 @@ struct DevScene {
     const float4* leaf_prims;
     const float4* prim_attr;
     const float4* prim_pos;
+    const uint2* entry_lists;       // ancestors of the primitives' home nodes (trav_enter, pt_wavefront.h)
+    const uint32_t* prim_entry;     // per primitive: list offset << 6 | entries (0: start at the root)
     const pt_material* materials;   // indexed by MODEL (material resolved on upload)
     const pt_texture* textures;
     const uint8_t* texels;

@@ -31,6 +31,7 @@
 #include <mutex>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "pt_integrator.h"
@@ -523,6 +524,8 @@ void select_device(int device) {
 struct pt_prep {
     std::vector<pth_kd_node> nodes;            // treelet order (see below)
     std::vector<float4> leaf, attr, pos;
+    std::vector<uint2> entry_lists;            // entry lists of the KD-tree (csrc/pt_wavefront.h trav_enter) ...
+    std::vector<uint32_t> prim_entry;          // ... and the word (list offset << 6 | entries) of every primitive
     std::vector<pt_material> model_mat;
     std::vector<pt_texture> textures;
     std::vector<uint8_t> texels;
@@ -708,13 +711,13 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
     // pair << 2 | axis), leaf (first record, n << 2 | 3) as before.
     std::vector<pth_kd_node>& tre = P.nodes;
     tre.assign(std::max<uint64_t>(kd.n_nodes, 1) + 1, pth_kd_node{0u, 0u});
+    std::vector<uint32_t> new_index(kd.n_nodes, 0xffffffffu);   // builder (DFS) node number -> device slot
     {
         const pth_kd_node* N = kd.nodes;
         const int H = 4;  // treelet height: 2 + 4 + 8 = 14 nodes = 112 B below the treelet root pair
         if (kd.n_nodes == 0) {
             tre[0] = pth_kd_node{0u, 3u};
         } else {
-            std::vector<uint32_t> new_index(kd.n_nodes, 0xffffffffu);
             new_index[0] = 0;
             uint32_t next = 2;  // pairs start at even indices; slot 1 pads the root
             std::vector<uint32_t> cluster_roots{0}, frontier, level;
@@ -739,7 +742,7 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
                     if ((N[n].w1 & 3u) != 3u) cluster_roots.push_back(n);
             }
             if (next > tre.size()) tre.resize(next);
-            if (next >= (1u << 30)) fail(PT_ERR_UNSUPPORTED, "KD-tree has too many nodes");
+            if (next >= (1u << 29)) fail(PT_ERR_UNSUPPORTED, "KD-tree has too many nodes");
             for (uint64_t n = 0; n < kd.n_nodes; ++n) {
                 pth_kd_node nd = N[n];
                 if ((nd.w1 & 3u) != 3u) nd.w1 = (new_index[n + 1] << 2) | (nd.w1 & 3u);
@@ -748,6 +751,81 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
             tre[1] = pth_kd_node{0u, 3u};
         }
     }
+    // ---- entry lists (trav_enter, csrc/pt_wavefront.h).  A path's next ray starts ON the primitive it just hit
+    // (origin = hit point + interpolated normal * 1e-5, mod.rs:266-268), deep inside the tree: of the ~23 nodes such a
+    // cast visits, the first ~15 are the descent from the root to the small node around its origin - a chain of
+    // dependent 8-byte fetches during which nothing is decided that the origin's whereabouts do not already say, except
+    // which far children the ray will come back to.  So every primitive gets its HOME NODE - the deepest node whose box
+    // holds every origin a hit on the primitive can produce - and the list of the home node's ancestors, root first:
+    // (split, far child << 3 | near child is the below child << 2 | axis).  The cast reads that list (contiguous, all
+    // loads in flight together), pushes the far children its ray reaches, and starts walking at the home node.  The
+    // lists are shared by the primitives of a home node (a few MB in all).  Nothing here is load-bearing for
+    // correctness: the cast checks that its origin lies on the near side of every listed plane and starts at the root
+    // otherwise, so the region below is an estimate that only has to be right most of the time.
+    P.prim_entry.assign(n_prims, 0u);
+    P.entry_lists.clear();
+    if (kd.n_nodes > 0 && n_prims > 0) {
+        const pth_kd_node* N = kd.nodes;
+        double ext = 0;
+        for (int a = 0; a < 3; ++a)
+            ext = std::max({ext, (double)fabsf(kd.bounds_min[a]), (double)fabsf(kd.bounds_max[a]), (double)fabsf(d.camera.transform[12 + a])});
+        const float eps = (float)(2.5e-7 * std::max(ext, 1e-3));   // ~2 ulps of the largest coordinate: the rounding of o + d * t
+        std::unordered_map<uint32_t, uint32_t> word_of_home;     // home node (builder numbering) -> entry word
+        uint32_t path[PT_KD_STACK + 1];
+        uint64_t q = 0;
+        for (uint32_t m = 0; m < d.n_models; ++m) {
+            const pt_model& mo = d.models[m];
+            const uint32_t cnt = mo.kind == PT_MODEL_MESH ? mo.tri_count : 1u;
+            for (uint32_t t = 0; t < cnt; ++t, ++q) {
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; ++a) {
+                    if (mo.kind == PT_MODEL_MESH) {
+                        const float* v = d.triangles + (size_t)(mo.tri_first + t) * 24;
+                        const float nl = fminf(fminf(v[3 + a], v[11 + a]), v[19 + a]), nh = fmaxf(fmaxf(v[3 + a], v[11 + a]), v[19 + a]);
+                        lo[a] = fminf(fminf(v[a], v[8 + a]), v[16 + a]) + 1.05e-5f * nl - eps;
+                        hi[a] = fmaxf(fmaxf(v[a], v[8 + a]), v[16 + a]) + 1.05e-5f * nh + eps;
+                    } else {   // a sphere's hits: on the surface, pushed 1e-5 out (entry hit) or in (exit hit, model.rs:49-62)
+                        lo[a] = mo.center[a] - mo.radius - 1.05e-5f - eps;
+                        hi[a] = mo.center[a] + mo.radius + 1.05e-5f + eps;
+                    }
+                }
+                uint32_t node = 0, depth = 0;
+                while (lo[0] == lo[0] && hi[0] == hi[0]) {   // (a NaN region stays at the root)
+                    const pth_kd_node nd = N[node];
+                    const uint32_t axis = nd.w1 & 3u;
+                    if (axis == 3u || depth >= 63u) break;
+                    float split;
+                    memcpy(&split, &nd.w0, 4);
+                    uint32_t next;
+                    if (hi[axis] < split) next = node + 1u;            // below child = next node (builder layout)
+                    else if (lo[axis] > split) next = nd.w1 >> 2;      // above child
+                    else break;
+                    path[depth++] = node;
+                    node = next;
+                }
+                auto it = word_of_home.find(node);
+                if (it == word_of_home.end()) {
+                    uint32_t word = 0u;
+                    if (depth > 0) {
+                        if (P.entry_lists.size() & 1u) P.entry_lists.push_back(make_uint2(0u, 0u));   // 16-byte aligned lists
+                        const uint64_t off = P.entry_lists.size();
+                        if (off + depth >= (1ull << 26)) fail(PT_ERR_UNSUPPORTED, "entry lists exceed 2^26 entries");
+                        for (uint32_t k = 0; k < depth; ++k) {
+                            const uint32_t anc = path[k], child = k + 1 < depth ? path[k + 1] : node;
+                            const bool near_below = child == anc + 1u;
+                            const uint32_t far_host = near_below ? (N[anc].w1 >> 2) : anc + 1u;
+                            P.entry_lists.push_back(make_uint2(N[anc].w0, (new_index[far_host] << 3) | (near_below ? 4u : 0u) | (N[anc].w1 & 3u)));
+                        }
+                        word = (uint32_t)(off << 6) | depth;
+                    }
+                    it = word_of_home.emplace(node, word).first;
+                }
+                P.prim_entry[q] = it->second;
+            }
+        }
+    }
+    if (P.entry_lists.size() & 1u) P.entry_lists.push_back(make_uint2(0u, 0u));
+    for (int k = 0; k < 8; ++k) P.entry_lists.push_back(make_uint2(0u, 0u));   // (the batched loads of trav_enter read up to 8 entries past a list's start)
     DevScene& D = P.dev;
     D.n_lights = d.n_lights;
     D.n_prims = (uint32_t)n_prims;
@@ -863,6 +941,8 @@ void scene_upload(const pt_prep& P, int device, pt_scene& s) {
     D.leaf_prims = s.upload(P.leaf.data(), P.leaf.size());
     D.prim_attr = s.upload(P.attr.data(), P.attr.size());
     D.prim_pos = s.upload(P.pos.data(), P.pos.size());
+    D.entry_lists = s.upload(P.entry_lists.data(), P.entry_lists.size());
+    D.prim_entry = s.upload(P.prim_entry.data(), P.prim_entry.size());
     D.materials = s.upload(P.model_mat.data(), P.model_mat.size());
     D.textures = s.upload(P.textures.data(), P.textures.size());
     D.texels = s.upload(P.texels.data(), P.texels.size());
@@ -1131,7 +1211,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         while (true) {
             multi_chunk = (uint64_t)cap < items_per_batch;
             const size_t lights = std::max(1u, s.dev.n_lights);
-            bool ok = w.queue[0].try_ensure((size_t)cap * 64u) && w.queue[1].try_ensure((size_t)cap * 64u) &&
+            bool ok = w.queue[0].try_ensure((size_t)cap * 68u) && w.queue[1].try_ensure((size_t)cap * 68u) &&   // (64 B + the entry word)
                       w.hits.try_ensure((size_t)cap * 20u) && w.shadow.try_ensure((size_t)cap * 64u) &&
                       w.contrib.try_ensure((size_t)cap * 16u * lights) && w.rng[0].try_ensure((size_t)cap * 32u) &&
                       (!(multi_chunk && wf_overlap) || w.rng[1].try_ensure((size_t)cap * 32u)) &&
@@ -1224,6 +1304,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     return (uint32_t)(e && *e ? atoi(e) : 0);
                 }();
                 W.sort_octants = wf_sort;
+                // PT_WF_ENTRY=1: casts of bounces >= 1 start at the home node of the primitive their ray leaves (trav_enter).
+                // Measured (profiles/r03_experiments.txt item 2): 31 % fewer node visits, the same time - off by default
+                static const uint32_t wf_entry = [] {
+                    const char* e = getenv("PT_WF_ENTRY");
+                    return (uint32_t)(e && *e ? atoi(e) != 0 : 0);
+                }();
+                W.use_entry = wf_entry;
 
                 W.refill_min = std::max(1u, std::min(64u, wf_refill));
                 W.walk_steps = wf_walk ? wf_walk : 20u;

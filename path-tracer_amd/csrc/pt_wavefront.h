@@ -74,6 +74,7 @@ struct WfParams {
     uint32_t walk_steps;  // node steps per walking phase
     uint32_t sort_octants;  // k_wf_shade: bit 0 - survivors of a workgroup step bucketed by direction octant; bit 1 - hits shaded in material order
     uint32_t defer_age;     // k_wf_trace, queue exhausted: casts older than this many loop iterations go to k_wf_trace_wide (0: never)
+    uint32_t use_entry;     // the queues carry entry words (trav_enter): casts of bounces >= 1 start at their primitive's home node
 };
 
 // A path queue of capacity `cap` records is two planes of 32 bytes per record (the casts read the first only, the misses
@@ -82,6 +83,9 @@ struct WfParams {
 //   path plane  q[2 cap + 2 i] = (thr.xyz, out_slot)  q[2 cap + 2 i + 1] = (colour.xyz, -)    <- patched by the shadow kernels
 PT_D const float4* wf_ray_rec(const float4* q, uint32_t i) { return q + (size_t)i * 2; }
 PT_D float4* wf_ray_rec(float4* q, uint32_t i) { return q + (size_t)i * 2; }
+// A third plane of 4 bytes per record: the entry word of the primitive the ray starts on (trav_enter; 0 = the root)
+PT_D const uint32_t* wf_entry_plane(const float4* q, uint32_t cap) { return (const uint32_t*)(q + (size_t)cap * 4); }
+PT_D uint32_t* wf_entry_plane(float4* q, uint32_t cap) { return (uint32_t*)(q + (size_t)cap * 4); }
 PT_D const float4* wf_path_rec(const float4* q, uint32_t cap, uint32_t i) { return q + ((size_t)cap + i) * 2; }
 PT_D float4* wf_path_rec(float4* q, uint32_t cap, uint32_t i) { return q + ((size_t)cap + i) * 2; }
 
@@ -336,6 +340,65 @@ PT_D bool trav_pop(Trav& T, const TravStack& st, float limit) {
     T.tmin = T.tmax;
     stack_get(st, T.sp, T.node, T.tmax);
     return !(T.tmin * T.key_scale > limit * PT_EXIT_REL + PT_EXIT_ABS);
+}
+
+// Start a cast whose origin lies on a primitive (every ray after the camera ray: origin = hit point + normal * 1e-5,
+// mod.rs:266-268) at that primitive's HOME NODE instead of the root (the lists: prep_create, pt_gpu.hip).  `word` =
+// list offset << 6 | entries; an entry = (split, far child << 3 | near is below << 2 | axis) of one ancestor of the home
+// node, root first.  What the walk from the root does at an ancestor whose near child (the one towards the home node)
+// holds the origin is decided by the plane parameter alone: the far child is pushed iff the ray reaches the plane
+// inside the current interval.  So the ~15 dependent node fetches of the descent become one contiguous read with every
+// load in flight at once, ~12 instructions per level instead of ~45, and the walk starts where the decisions start.
+// The leaves visited are a superset of the root walk's (same slack on the far side; an origin exactly ON a plane takes
+// both children where the root walk takes the one the ray heads into), and the accepted hit is the minimum of a total
+// order over all intersected primitives: the same bits.  The origin's side of every plane is CHECKED; a cast that fails
+// the check - a region estimate of the host that was too tight - walks from the root.
+#ifndef WF_ENTRY_BATCH
+#define WF_ENTRY_BATCH 8   // list entries loaded together (two registers each)
+#endif
+PT_D bool trav_enter(const DevScene& S, Trav& T, const TravStack& st, f3 o, f3 d, uint32_t word) {
+    if (!trav_start(S, T, o, d, 0.f)) return false;
+    const uint32_t count = word & 63u;
+    if (count == 0u) return true;
+    const uint4* list = (const uint4*)(S.entry_lists + (word >> 6));   // (16-byte aligned, padded: prep_create)
+    const float tmax0 = T.tmax;
+    float tmax = T.tmax;
+    int sp = 0;
+    uint32_t last_far = 0u, bad = 0u;
+    for (uint32_t base = 0; base < count; base += WF_ENTRY_BATCH) {
+        uint4 r[WF_ENTRY_BATCH / 2];
+#pragma unroll
+        for (int j = 0; j < WF_ENTRY_BATCH / 2; ++j) r[j] = list[(base >> 1) + j];   // (reads past the list stay inside the array)
+#pragma unroll
+        for (int j = 0; j < WF_ENTRY_BATCH; ++j) {
+            if (base + j < count) {
+                const uint32_t w0 = (j & 1) ? r[j >> 1].z : r[j >> 1].x, w1 = (j & 1) ? r[j >> 1].w : r[j >> 1].y;
+                const float split = __uint_as_float(w0);
+                const uint32_t axis = w1 & 3u;
+                const unsigned long long ax0 = __builtin_amdgcn_uicmp(axis, 0u, 32), ax1 = __builtin_amdgcn_uicmp(axis, 1u, 32);
+                const float o_a = wf_select(ax0, o.x, wf_select(ax1, o.y, o.z));
+                const float i_a = wf_select(ax0, T.inv.x, wf_select(ax1, T.inv.y, T.inv.z));
+                const float tplane = (split - o_a) * i_a;
+                // the origin must be on the near side of the plane (or in it)
+                bad |= (w1 & 4u) ? (o_a > split ? 1u : 0u) : (o_a < split ? 1u : 0u);
+                const bool push = !(tplane < 0.f) & !(tplane > __builtin_fmaf(tmax, PT_EXIT_REL, PT_EXIT_ABS));   // (a NaN parameter: both)
+                last_far = w1 >> 3;
+                if (push) {
+                    stack_push(st, sp, last_far, tmax);
+                    ++sp;
+                    tmax = tplane;
+                }
+            }
+        }
+    }
+    if (bad) {   // start at the root after all
+        T.tmax = tmax0;
+        return true;
+    }
+    T.node = last_far ^ 1u;   // sibling pairs are adjacent: (pair, pair + 1), pair even
+    T.sp = sp;
+    T.tmax = tmax;
+    return true;
 }
 
 // One node.  Returns 0 = still walking, 1 = holding a non-empty leaf (T.leaf), 2 = walk over.
@@ -695,6 +758,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                 idx = w;
                 f3 o, d;
                 bool valid_item;
+                uint32_t entry_word = 0u;
                 if (PRIMARY) {
                     const uint2 sc = *(const uint2*)(rng_planes + idx);  // jittered screen position (k_wf_rng)
                     valid_item = sc.x != WF_ITEM_INVALID;
@@ -710,6 +774,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                     // live paths only - items outside the image never leave the bounce-0 kernels)
                     const float4* q = wf_ray_rec(queue, idx);
                     float4 q0 = q[0], q1 = q[1];
+                    entry_word = W.use_entry ? wf_entry_plane(queue, W.cap)[idx] : 0u;
                     o = mk3(q0.x, q0.y, q0.z);
                     d = mk3(q0.w, q1.x, q1.y);
                     valid_item = true;
@@ -729,7 +794,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                 best.pid = 0xffffffffu;
                 active = true;
                 // outside the image / misses the scene box: answered as "no hit" below
-                lstate = (!valid_item || !trav_start(S, T, o, d, 0.f)) ? WF_LANE_DONE : WF_LANE_WALK;
+                lstate = (!valid_item || !(PRIMARY ? trav_start(S, T, o, d, 0.f) : trav_enter(S, T, st, o, d, entry_word))) ? WF_LANE_DONE : WF_LANE_WALK;
             }
         }
         WF_STAMP(st_refill);
@@ -1352,6 +1417,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
         qr[1] = make_float4(next_d.y, next_d.z, __uint_as_float(item), __uint_as_float((draw & 0xffffu) | ((bounce + 1) << 16)));
         qp[0] = make_float4(next_thr.x, next_thr.y, next_thr.z, __uint_as_float(out_slot));
         qp[1] = make_float4(color.x, color.y, color.z, 0.f);  // colour is patched by the shadow kernels
+        if (W.use_entry) wf_entry_plane(queue_out, W.cap)[next_idx] = S.prim_entry[PT_PRIM_INDEX(h.pid)];
     }
     if (to_shadow) {
         float4* sq = shadow_q + (size_t)sh_idx * 4;

@@ -48,6 +48,8 @@ SETTINGS = [
     {"PT_SHADE_BLOCKS_B0": "3", "PT_SHADE_BLOCKS": "1"},   # resident-only shade grids
     {"PT_WF_WALK": "3", "PT_WF_REFILL": "48"},              # odd traversal parameters
     {"PT_TILE_ORDER": "morton"},
+    {"PT_WF_ENTRY": "1"},                 # casts of bounces >= 1 start at their primitive's home node (entry lists)
+    {"PT_WF_ENTRY": "1", "PT_OG": "0"},   # ... on the KD-only pipeline
     {"PT_OG_BUDGET_GIB": "0.02"},         # grid memory budget of 20 MB: a coarser camera grid, the light on the KD-tree
     {"PT_OG_BUDGET_GIB": "0.001"},        # ... of 1 MB: no grid fits
 ]
