@@ -48,11 +48,31 @@ def bytes_per_sample(c, spp):
     return floor, ceiling, dict(R_seg=r_seg, R_sh=r_sh, V=v, T=t, H=h)
 
 
+def count_gpus():
+    """GPUs of this node from the kernel driver's topology files (/sys/class/kfd): no GPU runtime is loaded, let alone
+    initialised, by the parent that only starts the ranks.  A *_VISIBLE_DEVICES list narrows the count."""
+    n = 0
+    try:
+        for node in sorted(Path("/sys/class/kfd/kfd/topology/nodes").iterdir()):
+            props = dict(line.split(None, 1) for line in (node / "properties").read_text().splitlines() if " " in line)
+            if int(props.get("simd_count", "0")) > 0:     # (CPU nodes have no SIMDs)
+                n += 1
+    except OSError:
+        n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""])) if n else len([x for x in v.split(",") if x.strip() != ""])
+    return n
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher around it: start N ranks (one per GPU) as children, before this
     process touches the GPU (it never does), and hand their exit status on."""
-    import torch  # device_count() does not initialise the GPU on this image
-    have = torch.cuda.device_count()
+    have = count_gpus()
+    if have < args.gpus:   # (no topology files in this container: ask the runtime - counting devices does not initialise them)
+        import torch
+        have = max(have, torch.cuda.device_count())
     if have < args.gpus and "PT_BENCH_DEVICE" not in os.environ:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible")
     with socket.socket() as s:
@@ -154,8 +174,18 @@ def main():
                                tile_w=tile, tile_h=tile)
     ev_steps = max(1, args.steps if world == 1 else 1)
 
+    # the frame of this rank and - N > 1 - the exchange, timed with events on the launch stream (every timed step)
+    ev_render = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                 for _ in range(args.steps)]
+    step_no = [-1]
+
     def step(with_events=True):
+        ks = step_no[0]   # timed step number, -1 during the warm-up
+        if ks >= 0:
+            ev_render[ks][0].record()
         gscene.render_device(prof, opts if with_events else opts_plain, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
+        if ks >= 0:
+            ev_render[ks][1].record()
         if with_events:
             tm = gscene.timing().as_dict()
             for k in stage_ms:
@@ -171,6 +201,8 @@ def main():
                 gathered.copy_(torch.cat(parts))
             pta.check_gpu(lib.pt_assemble_tiles(C.byref(prof), world, tile, tile, slice_pixels, 3,
                                                 gathered.data_ptr(), image.data_ptr(), stream))
+        if ks >= 0:
+            ev_render[ks][2].record()
 
     def fence():
         if world > 1:
@@ -186,9 +218,18 @@ def main():
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        step_no[0] = k
         step(with_events=k < ev_steps)
     fence()
     elapsed = time.perf_counter() - t0
+    render_ms = sum(a.elapsed_time(b) for a, b, _ in ev_render) / args.steps     # this rank's frame (device time)
+    gather_ms = sum(b.elapsed_time(c) for _, b, c in ev_render) / args.steps if world > 1 else 0.0
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([render_ms, gather_ms], device=cdev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [[round(float(x[0]), 3), round(float(x[1]), 3)] for x in every]
     if world > 1:
         t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -218,9 +259,17 @@ def main():
             per_frame = launches["bounce0_launches"] // ev_steps
             b0_bytes = (n_items * 160 + counters["bounce0_shadow_rays"] * 104 + counters["bounce0_tris"] * 36
                         + counters["bounce0_hits"] * 160 + n_items * 12)
+            # ... and what of that the fused kernel has to MOVE: the ray, hit and shadow records stay in registers, so what
+            # is left is the primitives tested (36 B + the 8-byte list entry that named them), the attribute and material
+            # records of the shaded hits, two grid-cell words per cast, and the output - a 12-byte sample, or for a path that
+            # goes on (at most one per hit, at most the casts of the later bounces) the 64-byte record + 16 B of RNG words
+            survivors = min(counters["bounce0_hits"], max(0, counters["segments"] - n_items))
+            b0_moved = (counters["bounce0_tris"] * 44 + counters["bounce0_hits"] * 160
+                        + (n_items + counters["bounce0_shadow_rays"]) * 8 + (n_items - survivors) * 12 + survivors * 80)
             kernels["k_wf_shade<GRID> (bounce 0: ChaCha12 block + camera cast + shading + shadow casts)"] = dict(
                 ms_per_frame=stage_ms["bounce0_ms"] / ev_steps, launches_per_frame=per_frame,
-                bytes_per_frame=b0_bytes, units_per_launch=n_items // max(1, per_frame), unit="path samples")
+                bytes_per_frame=b0_bytes, moved_bytes_per_frame=b0_moved,
+                units_per_launch=n_items // max(1, per_frame), unit="path samples")
         fused = bool(launches["bounce0_launches"])
         trace_segments = counters["segments"] - (n_items if fused else 0)
         # closest-hit primitive tests of the KD casts (trace_tris also holds the camera casts of the fused kernel)
@@ -278,6 +327,30 @@ def main():
             except Exception:
                 traffic = None
         copy_gbs = pta.measure_copy_bandwidth(local_rank, 2 << 30, 5)   # achievable HBM rate on this box
+        # What the kernel is bound by, from the PMC passes of the same workload (profiles/latest_traffic.json): the contract's
+        # `bound` below stays "hbm" (there is no contraction, so not "mfma"), this says which ceiling the counters show
+        lanes = None
+        if traffic_src:
+            short = name.split("<")[0].split(" ")[0]
+            per_kernel = json.loads(tf.read_text()).get("kernels", {})
+            key = next((k for k in per_kernel if k.split("<")[0] == short and ("GRID" in k) == ("<GRID>" in name)), None)
+            lanes = per_kernel.get(key, {}).get("active_lanes_per_valu_inst") if key else None
+        traffic_frac_now = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
+        if valu_rate is not None and valu_rate >= 0.8:
+            bound_measured = {"bound": "valu_issue", "counter": "SQ_INSTS_VALU / (SQ_BUSY_CYCLES per CU)", "value": valu_rate,
+                              "ceiling": 1.0, "frac": round(valu_rate, 3), "active_lanes_per_valu_inst": lanes,
+                              "note": "a wave64 vector instruction occupies its SIMD for 4 cycles: 1.0 per CU-cycle is the issue ceiling"}
+        elif traffic_frac_now is not None and traffic_frac_now >= 0.6:
+            bound_measured = {"bound": "hbm", "counter": "2 x FETCH_SIZE + WRITE_SIZE", "value": round(traffic_frac_now * HBM_PEAK_GBS, 1),
+                              "ceiling": HBM_PEAK_GBS, "frac": round(traffic_frac_now, 3)}
+        elif valu_rate is not None:
+            bound_measured = {"bound": "latency_of_dependent_scattered_fetches", "counter": "SQ_ACTIVE_INST_VALU lanes, SQ_WAIT_INST_ANY",
+                              "value": lanes, "ceiling": 64, "frac": round((lanes or 0) / 64.0, 3), "valu_insts_per_cu_cycle": valu_rate,
+                              "note": "lanes active per vector instruction: the wavefront waits for its slowest lane's fetch"}
+        else:
+            bound_measured = None
+        moved = dom.get("moved_bytes_per_frame", dom["bytes_per_frame"]) / max(1, dom["launches_per_frame"])
+        moved_gbs = moved / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_src,
@@ -286,6 +359,11 @@ def main():
                     # what the kernel actually runs against (PMC): vector-instruction issue, 1.0 per CU-cycle = the ceiling
                     "valu_insts_per_cu_cycle": valu_rate,
                     "peak_measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
+                    # without the record bytes a fused kernel keeps in registers: cannot exceed the copy kernel
+                    "moved_bytes_per_launch": round(moved), "moved_GBps": round(moved_gbs, 1),
+                    "moved_bytes_frac": round(moved_gbs / HBM_PEAK_GBS, 5),
+                    "moved_frac_of_measured_copy": round(moved_gbs / copy_gbs, 5),
+                    "bound_measured": bound_measured,
                     "avg_launch_ms": round(avg_ms, 4), "steps_timed_with_events": ev_steps, "launches_per_step": dom["launches_per_frame"],
                     "units_per_launch": dom["units_per_launch"], "unit_name": dom["unit"],
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
@@ -342,22 +420,39 @@ def main():
         pta.check_host(pta.host_lib().pth_png_write_rgb8(os.fsencode(args.save_png), args.width, args.height,
                                                          img.ctypes.data))
 
+    dev_name = f"{local_rank}:{torch.cuda.get_device_name(local_rank)}"
+    devices = [dev_name]
+    if world > 1:
+        names = [None] * world
+        dist.all_gather_object(names, dev_name)
+        devices = names
     if rank == 0:
         out = {
             "metric": "Msamples/sec (WxHxspp/s), PS5 stand-in scene, Cook-Torrance + FILMIC",
-            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 3), "unit": "Msamples/s",
+            "n_gpus": world if args.backend == "nccl" or world == 1 else len(set(devices)), "n_ranks": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PS5 stand-in {scene.n_triangles} triangles (generator seed 0, flags "
                                    f"{args.scene_flags}), {args.width}x{args.height}, {args.spp} spp, "
                                    f"{args.bounces} bounces, COOK_TORRANCE, {args.tonemap}",
-                       "parallelism": f"{world} x tile-sharded (32x32 interleaved)" + (", RCCL all-gather of u8 framebuffer" if world > 1 else ""),
+                       "parallelism": f"{world} x tile-sharded (32x32 interleaved)" + (
+                           "" if world == 1 else ", RCCL all-gather of u8 framebuffer" if args.backend == "nccl"
+                           else f", {args.backend} all-gather through host memory (REHEARSAL on {len(set(devices))} GPU(s), not an RCCL run)"),
                        "kd": {k: info[k] for k in ("n_prims", "n_kd_nodes", "n_kd_leaves", "n_leaf_refs", "kd_depth", "n_edge_prims")},
                        "origin_grids": {k: info[k] for k in ("cam_grid_res", "light_grids", "grid_refs")},
                        "setup_seconds": round(setup_s, 2), "kd_build_seconds": round(info["kd_build_seconds"], 2),
                        "grid_build_seconds": round(info["grid_build_seconds"], 2)},
             "roofline": roofline,
+            "bound_measured": roofline["bound_measured"] if roofline else None,
+            "moved_bytes_frac": roofline["moved_bytes_frac"] if roofline else None,
             "cpu_baseline": cpu,
+            "backend": ("rccl (torch.distributed nccl)" if args.backend == "nccl" else args.backend) if world > 1 else "none (one GPU)",
+            "devices": devices,
+            "per_rank_ms": None if per_rank is None else {
+                "render": {"max": max(r[0] for r in per_rank), "min": min(r[0] for r in per_rank), "ranks": [r[0] for r in per_rank]},
+                "gather_and_assemble": {"max": max(r[1] for r in per_rank), "min": min(r[1] for r in per_rank)}},
+            "render_ms_rank0": round(render_ms, 3),
         }
         if counters:
             out["counters"] = counters
