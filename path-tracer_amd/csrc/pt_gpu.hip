@@ -470,7 +470,7 @@ struct pt_scene {
     bool ortho_light_grids = false;   // some light grid is orthographic (a directional light): kernel variants DIRL
     mutable pt_timing timing{};
     mutable pt_counters counters{};
-    mutable DeviceBuffer accum_scratch, tile_table, counter_buf, staging_buf;
+    mutable DeviceBuffer accum_scratch, counter_buf, staging_buf;
     // The queues of the chunk of work items in flight.  The shadow casts of bounce b run on a side stream
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
@@ -481,7 +481,10 @@ struct pt_scene {
     mutable WfPipe pipe;
     mutable int trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
     mutable uint32_t wf_cap_ok = 0;   // largest queue capacity the device provided so far (0: not tried)
-    mutable std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> tile_key{0, 0, 0, 0, 0, 0};
+    // tile tables of the sharded renders, one per configuration (image size, rank, count, tile size) and never rewritten:
+    // pt_render_device is asynchronous, two calls for different ranks may be in flight on the caller's streams at once
+    typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> TileKey;
+    mutable std::map<TileKey, std::unique_ptr<DeviceBuffer>> tile_tables;
     mutable std::vector<hipEvent_t> events;
 
     ~pt_scene() {
@@ -1039,7 +1042,12 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     uint32_t tile_order_base = 0, tile_k_base = 0;
     if (o.shard_count > 1 || morton) {
         auto key = std::make_tuple(p.width, p.height, o.shard_rank, o.shard_count, o.tile_w, o.tile_h);
-        if (key != s.tile_key || !s.tile_table.p) {
+        auto found = s.tile_tables.find(key);
+        if (found == s.tile_tables.end()) {
+            if (s.tile_tables.size() >= 256) {   // (a caller cycling through hundreds of configurations: start over, idle)
+                HIP_CHECK(hipDeviceSynchronize());
+                s.tile_tables.clear();
+            }
             std::vector<uint32_t> table(tm.offsets);
             table.insert(table.end(), tm.tiles.begin(), tm.tiles.end());   // global tile numbers (tile_k_base)
             if (morton) {
@@ -1060,11 +1068,12 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 std::sort(order.begin(), order.end());
                 for (auto& e : order) table.push_back(e.second);
             }
-            s.tile_table.ensure(table.size() * 4);
-            HIP_CHECK(hipMemcpy(s.tile_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice));
-            s.tile_key = key;
+            auto buf = std::make_unique<DeviceBuffer>();
+            buf->ensure(table.size() * 4);
+            HIP_CHECK(hipMemcpy(buf->p, table.data(), table.size() * 4, hipMemcpyHostToDevice));   // (a fresh buffer: nobody reads it yet)
+            found = s.tile_tables.emplace(key, std::move(buf)).first;
         }
-        d_tiles = (const uint32_t*)s.tile_table.p;
+        d_tiles = (const uint32_t*)found->second->p;
         tile_k_base = (uint32_t)tm.offsets.size();
         if (morton) tile_order_base = (uint32_t)(tm.offsets.size() + tm.tiles.size());
     }

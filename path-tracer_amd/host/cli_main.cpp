@@ -17,7 +17,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "ptgpu.h"
@@ -184,10 +187,15 @@ int run_render(int argc, char** argv) {
 
     if (devices.size() > 1) {
         // One host thread per GPU.  The host work (KD-tree, origin grids) is done ONCE (pt_prep) and uploaded to every
-        // device; shard k of N = tiles k, k + N, ... (the global pixel index stays in the RNG seed, so the assembled
-        // image equals the single-GPU one bit for bit).  Distinct devices exchange their packed u8 slices with one
-        // RCCL all-gather over xGMI and scatter them on the device (pt_gather_tiles); a device list with repeats
-        // (several shards on one GPU: a rehearsal) is assembled on the host, RCCL does not allow duplicates.
+        // device; tile (tx, ty) of the 32x32 grid goes to shard (tx + ty * s) mod N (diagonal stripes, pt_local_pixel_map;
+        // the global pixel index stays in the RNG seed, so the assembled image equals the single-GPU one bit for bit).
+        // Distinct devices exchange their packed u8 slices with one RCCL all-gather over xGMI and scatter them on the
+        // device (pt_gather_tiles); a device list with repeats (several shards on one GPU: a rehearsal) is assembled on
+        // the host, RCCL does not allow duplicates.
+        // Two phases with a barrier between them: every worker uploads its scene first, and the collective phase is
+        // entered only if ALL of them succeeded - a worker that failed would never arrive at the all-gather and the
+        // others would wait for it forever.  A failure INSIDE the collective phase (after the peers may already be
+        // enqueued in ncclAllGather) ends the process with the message and exit code 2 instead of joining.
         const uint32_t n = (uint32_t)devices.size();
         pt_prep* prep = nullptr;
         if (pt_prep_create(pth_scene_desc(hscene), &prep) != PT_OK) die(pt_last_error());
@@ -211,16 +219,29 @@ int run_render(int argc, char** argv) {
         std::vector<std::vector<uint32_t>> map(n);
         std::vector<std::string> error(n);
         std::vector<uint8_t> rgb((size_t)profile.width * profile.height * 3);
+        std::mutex bar_mutex;
+        std::condition_variable bar_cv;
+        uint32_t arrived = 0, failed = 0;
         auto worker = [&](uint32_t k) {
             pt_scene* sc = nullptr;
             auto check = [&](int rc) {   // (the message is thread-local: read it on this thread)
                 if (rc != PT_OK && error[k].empty()) error[k] = pt_last_error();
                 return rc == PT_OK;
             };
-            if (check(pt_scene_create_from_prep(prep, devices[k], &sc))) {
+            const bool up = check(pt_scene_create_from_prep(prep, devices[k], &sc));
+            {   // barrier: all scenes are resident, or nobody renders
+                std::unique_lock<std::mutex> lock(bar_mutex);
+                if (!up) ++failed;
+                if (++arrived == n) bar_cv.notify_all();
+                else bar_cv.wait(lock, [&] { return arrived == n; });
+            }
+            if (up && failed == 0) {
                 if (distinct) {
-                    if (check(pt_render_gathered(sc, comms[k], &profile, &opts[k], slice_pixels, k == 0 ? rgb.data() : nullptr)))
-                        (void)0;
+                    if (!check(pt_render_gathered(sc, comms[k], &profile, &opts[k], slice_pixels, k == 0 ? rgb.data() : nullptr))) {
+                        fprintf(stderr, "Error: %s\n", error[k].c_str());   // (the peers may be inside the all-gather: do not join them)
+                        fflush(stderr);
+                        _exit(2);
+                    }
                 } else {
                     uint64_t count = pt_local_pixel_count(&profile, &opts[k]);
                     map[k].resize(count);

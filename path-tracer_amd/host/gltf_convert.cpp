@@ -20,6 +20,7 @@
 // reported as unsupported).  No reference test covers the converter: parity unpinned.
 #include <sys/stat.h>
 
+#include <cerrno>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -635,8 +636,14 @@ void convert(const std::string& input, const std::string& out_dir) {
     struct stat st;
     if (stat(out_dir.c_str(), &st) == 0) {
         if (!S_ISDIR(st.st_mode)) fail(PT_ERR_IO, "'%s' is not a directory", out_dir.c_str());   // gltf.rs:153-155
-    } else if (mkdir(out_dir.c_str(), 0755) != 0) {
-        fail(PT_ERR_IO, "cannot create directory %s", out_dir.c_str());
+    } else {   // fs::create_dir_all (gltf.rs:152): every missing component of the path
+        for (size_t pos = 0; pos != std::string::npos;) {
+            pos = out_dir.find('/', pos + 1);
+            const std::string part = out_dir.substr(0, pos);
+            if (part.empty()) continue;
+            if (mkdir(part.c_str(), 0755) != 0 && errno != EEXIST)
+                fail(PT_ERR_IO, "cannot create directory %s: %s", part.c_str(), strerror(errno));
+        }
     }
     pth_scene sc;
     Converter cv(sc);

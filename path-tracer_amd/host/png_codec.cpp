@@ -45,6 +45,7 @@ void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32
     uint32_t w = 0, h = 0;
     int depth = 0, ctype = -1, interlace = 0;
     std::vector<uint8_t> idat, plte;
+    std::vector<uint8_t> trns;   // tRNS: palette alphas (type 3) / the transparent grey or colour (types 0, 2), big-endian u16
     bool seen_ihdr = false, seen_iend = false;
     while (pos + 12 <= len && !seen_iend) {
         uint32_t clen = be32(data + pos);
@@ -61,6 +62,8 @@ void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32
             seen_ihdr = true;
         } else if (!memcmp(type, "PLTE", 4)) {
             plte.assign(body, body + clen);
+        } else if (!memcmp(type, "tRNS", 4)) {
+            trns.assign(body, body + clen);
         } else if (!memcmp(type, "IDAT", 4)) {
             idat.insert(idat.end(), body, body + clen);
         } else if (!memcmp(type, "IEND", 4)) {
@@ -153,26 +156,36 @@ void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32
             bool is_gray = false;
             if (ctype == 4) a = to8(sample(row, (size_t)x * channels + 1));
             if (ctype == 6) a = to8(sample(row, (size_t)x * channels + 3));
+            // tRNS (what the image crate's into_rgba8 carries for files without an alpha channel): one alpha per palette
+            // entry, or ONE sample value (at the file's bit depth) that is fully transparent
             if (ctype == 0 || ctype == 4) {
-                r = g = b = to8(sample(row, (size_t)x * channels));
+                const uint32_t v = sample(row, (size_t)x * channels);
+                r = g = b = to8(v);
                 is_gray = true;
+                if (ctype == 0 && trns.size() >= 2 && v == (((uint32_t)trns[0] << 8) | trns[1])) a = 0;
             } else if (ctype == 3) {
                 uint32_t idx = sample(row, x);
                 if ((size_t)idx * 3 + 2 >= plte.size()) fail(PT_ERR_PARSE, "palette index out of range");
                 r = plte[idx * 3];
                 g = plte[idx * 3 + 1];
                 b = plte[idx * 3 + 2];
+                if (idx < trns.size()) a = trns[idx];
             } else {
-                r = to8(sample(row, (size_t)x * channels));
-                g = to8(sample(row, (size_t)x * channels + 1));
-                b = to8(sample(row, (size_t)x * channels + 2));
+                const uint32_t vr = sample(row, (size_t)x * channels), vg = sample(row, (size_t)x * channels + 1),
+                               vb = sample(row, (size_t)x * channels + 2);
+                r = to8(vr);
+                g = to8(vg);
+                b = to8(vb);
+                if (ctype == 2 && trns.size() >= 6 && vr == (((uint32_t)trns[0] << 8) | trns[1]) &&
+                    vg == (((uint32_t)trns[2] << 8) | trns[3]) && vb == (((uint32_t)trns[4] << 8) | trns[5]))
+                    a = 0;
             }
             uint8_t* o = out + ((size_t)y * w + x) * want;
             if (want >= 3) {
                 o[0] = r;
                 o[1] = g;
                 o[2] = b;
-                if (want == 4) o[3] = a;   // (into_rgba8: opaque when the file has no alpha channel; tRNS is not read)
+                if (want == 4) o[3] = a;   // (into_rgba8: opaque when the file has neither an alpha channel nor tRNS)
             } else {
                 o[0] = is_gray ? r : (uint8_t)((2126u * r + 7152u * g + 722u * b) / 10000u);
             }

@@ -168,7 +168,7 @@ def test_convert_glb_through_the_cli(pta, tmp_path):
     glb = (b"glTF" + struct.pack("<II", 2, 12 + 8 + len(js) + 8 + len(blob)) + struct.pack("<II", len(js), 0x4E4F534A) + js +
            struct.pack("<II", len(blob), 0x004E4942) + blob)
     (tmp_path / "scene.glb").write_bytes(glb)
-    out = tmp_path / "converted"
+    out = tmp_path / "a" / "b" / "converted"      # create_dir_all (gltf.rs:152): the missing parents too
     r = subprocess.run([str(CLI), "convert", str(tmp_path / "scene.glb"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     check_isf(pta, out)

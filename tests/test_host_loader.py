@@ -152,6 +152,28 @@ def test_png_other_formats_via_pil(pta, tmp_path):
         assert np.array_equal(got, np.asarray(im.convert("RGB"))), name
 
 
+def test_png_trns_becomes_alpha(pta, tmp_path):
+    """tRNS - per-entry alphas of a palette, or the one transparent grey / colour - comes out as the alpha channel of an
+    RGBA decode, as the image crate's into_rgba8 delivers it (the glTF converter splits it into alpha_tex_N.png,
+    gltf.rs:27-45).  PIL is the yardstick."""
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    pal = Image.fromarray(rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)).quantize(8)
+    pal.save(tmp_path / "pal.png", transparency=bytes([0, 60, 120, 255, 200, 255, 17, 99]))
+    grey = Image.fromarray(rng.integers(0, 4, (7, 5), dtype=np.uint8) * 85)
+    grey.save(tmp_path / "grey.png", transparency=85)
+    rgb = Image.fromarray(rng.integers(0, 2, (7, 5, 3), dtype=np.uint8) * 255)
+    rgb.save(tmp_path / "rgb.png", transparency=(255, 0, 255))
+    for name in ("pal.png", "grey.png", "rgb.png"):
+        w, h, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+        pta.check_host(pta.host_lib().pth_png_read(str(tmp_path / name).encode(), 4, C.byref(w), C.byref(h), C.byref(px)))
+        got = np.ctypeslib.as_array(px, (7, 5, 4)).copy()
+        pta.host_lib().pth_free(px)
+        want = np.asarray(Image.open(tmp_path / name).convert("RGBA"))
+        assert np.array_equal(got, want), name
+        assert (got[..., 3] < 255).any() and (got[..., 3] > 0).any(), name
+
+
 def test_texture_cache_and_sharing(pta, tmp_path):
     from PIL import Image
     Image.fromarray(np.full((4, 4, 3), 200, np.uint8)).save(tmp_path / "t.png")
