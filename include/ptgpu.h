@@ -351,6 +351,12 @@ typedef struct pt_hit {
 /* rays: n x 6 f32 (origin3, direction3), HOST pointers. */
 int pt_trace_rays(const pt_scene* scene, const float* rays, uint64_t n, pt_hit* out);
 
+/* The first entry of ray_cast() through the wavefront integrator's own cast kernel (k_wf_trace; the rays of bounces
+ * >= 1 of every frame go through it).  mode bit 0: start at the home node of the primitive the ray leaves
+ * (start_prims[i], entry lists); bit 1: hand every cast to the cooperative kernel k_wf_trace_wide. */
+int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint32_t* start_prims, uint64_t n,
+                            uint32_t mode, pt_hit* out);
+
 /* Up to max_hits hits per ray in the reference's sorted order (all hits,
  * stable by (dist, primitive order)); counts[i] = number written. */
 int pt_trace_rays_all(const pt_scene* scene, const float* rays, uint64_t n, uint32_t max_hits,

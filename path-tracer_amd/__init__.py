@@ -175,7 +175,7 @@ HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_s
 GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_prep_create", "pt_prep_destroy", "pt_scene_create_from_prep",
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_gather_tiles", "pt_render_gathered", "pt_local_pixel_count", "pt_local_pixel_map",
                "pt_render", "pt_render_device", "pt_debug_render", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
-               "pt_scene_get_info", "pt_trace_rays", "pt_trace_rays_all", "pt_intersect_triangles",
+               "pt_scene_get_info", "pt_trace_rays", "pt_trace_rays_wavefront", "pt_trace_rays_all", "pt_intersect_triangles",
                "pt_rng_words", "pt_eval_math", "pt_measure_copy_bandwidth", "pt_measure_gather_rate", "pt_last_error",
                "pt_version"]
 
@@ -256,6 +256,7 @@ def gpu_lib():
         L.pt_get_counters.argtypes = [vp, C.POINTER(Counters)]
         L.pt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
         L.pt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp]
+        L.pt_trace_rays_wavefront.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, vp]
         L.pt_trace_rays_all.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
         L.pt_intersect_triangles.argtypes = [C.c_int, vp, vp, C.c_uint64, vp]
         L.pt_rng_words.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]
@@ -522,6 +523,16 @@ class GpuScene:
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         out = np.zeros(len(rays), dtype=HIT_DTYPE)
         check_gpu(self.lib.pt_trace_rays(self.handle, rays.ctypes.data, len(rays), out.ctypes.data))
+        return out
+
+    def trace_wavefront(self, rays, start_prims=None, mode=0):
+        """Closest hits through k_wf_trace itself (mode bit 0: entry lists from start_prims, bit 1: k_wf_trace_wide)."""
+        import numpy as np
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros(len(rays), dtype=HIT_DTYPE)
+        sp = None if start_prims is None else np.ascontiguousarray(start_prims, np.uint32)
+        check_gpu(self.lib.pt_trace_rays_wavefront(self.handle, rays.ctypes.data, None if sp is None else sp.ctypes.data,
+                                                   len(rays), mode, out.ctypes.data))
         return out
 
     def trace_all(self, rays, max_hits=8):

@@ -468,6 +468,7 @@ struct pt_scene {
     std::vector<void*> allocations;
     pt_scene_info info{};
     bool ortho_light_grids = false;   // some light grid is orthographic (a directional light): kernel variants DIRL
+    std::vector<uint32_t> host_prim_entry;
     mutable pt_timing timing{};
     mutable pt_counters counters{};
     mutable DeviceBuffer accum_scratch, counter_buf, staging_buf;
@@ -946,6 +947,7 @@ void scene_upload(const pt_prep& P, int device, pt_scene& s) {
     D.prim_pos = s.upload(P.pos.data(), P.pos.size());
     D.entry_lists = s.upload(P.entry_lists.data(), P.entry_lists.size());
     D.prim_entry = s.upload(P.prim_entry.data(), P.prim_entry.size());
+    s.host_prim_entry = P.prim_entry;   // (test hook pt_trace_rays_wavefront)
     D.materials = s.upload(P.model_mat.data(), P.model_mat.size());
     D.textures = s.upload(P.textures.data(), P.textures.size());
     D.texels = s.upload(P.texels.data(), P.texels.size());
@@ -1978,6 +1980,83 @@ int pt_trace_rays(const pt_scene* scene, const float* rays, uint64_t n, pt_hit* 
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());
         d_out.fetch(out, n);
+    });
+}
+
+// The same through the WAVEFRONT integrator's own cast kernel (k_wf_trace: persistent lanes, resumable walk with the
+// LDS stack and tree top, optional hand-over to k_wf_trace_wide) - the kernel the rays of bounces >= 1 of every frame
+// go through.  mode bit 0: entry lists (trav_enter, the primitive each ray starts on in start_prims); bit 1: every
+// cast is handed to k_wf_trace_wide as early as possible.
+int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint32_t* start_prims, uint64_t n, uint32_t mode, pt_hit* out) {
+    return guarded([&] {
+        if (!scene || !rays || !out) fail(PT_ERR_INVALID, "pt_trace_rays_wavefront: null argument");
+        if ((mode & 1u) && !start_prims) fail(PT_ERR_INVALID, "pt_trace_rays_wavefront: mode 1 needs start_prims");
+        if (n == 0) return;
+        if (n >= (1ull << 28)) fail(PT_ERR_INVALID, "pt_trace_rays_wavefront: too many rays");
+        HIP_CHECK(hipSetDevice(scene->device));
+        const uint32_t cap = (uint32_t)((n + 63) & ~63ull);
+        std::vector<float4> q((size_t)cap * 4 + (cap + 3) / 4, make_float4(0, 0, 0, 0));
+        uint32_t* entry = (uint32_t*)(q.data() + (size_t)cap * 4);
+        for (uint64_t i = 0; i < n; ++i) {
+            const float* r = rays + 6 * i;
+            uint32_t item = (uint32_t)i, draw = 1u << 16;
+            float fi, fd;
+            memcpy(&fi, &item, 4);
+            memcpy(&fd, &draw, 4);
+            q[2 * i] = make_float4(r[0], r[1], r[2], r[3]);
+            q[2 * i + 1] = make_float4(r[4], r[5], fi, fd);
+            if (mode & 1u) {
+                if (start_prims[i] >= scene->dev.n_prims) fail(PT_ERR_INVALID, "pt_trace_rays_wavefront: start primitive out of range");
+                entry[i] = scene->host_prim_entry[start_prims[i]];
+            }
+        }
+        Staged<float4> d_q(q.data(), q.size());
+        std::vector<WfCounters> ctr(3);
+        memset(ctr.data(), 0, sizeof(WfCounters) * 3);
+        ctr[1].queue_count = (uint32_t)n;
+        Staged<WfCounters> d_ctr(ctr.data(), 3);
+        Staged<uint4> d_hits(nullptr, (size_t)cap * 2);   // 4 B + 16 B per entry
+        int n_cu = 0;
+        HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, scene->device));
+        const uint32_t blocks = (uint32_t)std::max(1, n_cu) * 4u;
+        Staged<uint32_t> d_def(nullptr, (size_t)blocks * WF_THREADS);
+        WfParams W{};
+        W.n_items = (uint32_t)n;
+        W.cap = cap;
+        W.bounce = 1;
+        W.refill_min = 16;
+        W.walk_steps = 12;
+        W.defer_age = (mode & 2u) ? 1u : 0u;
+        W.use_entry = mode & 1u;
+        hipLaunchKernelGGL((k_wf_trace<false, false, false>), dim3(blocks), dim3(WF_THREADS), 0, 0, scene->dev, W, (const uint32_t*)nullptr,
+                           d_q.d, d_hits.d, (const uint4*)nullptr, (uint32_t*)nullptr, d_def.d, d_ctr.d, (DevCounters*)nullptr);
+        HIP_CHECK(hipGetLastError());
+        if (W.defer_age) {
+            hipLaunchKernelGGL((k_wf_trace_wide<false>), dim3((uint32_t)std::max(1, n_cu) * 4u), dim3(WF_THREADS), 0, 0, scene->dev, W,
+                               (const float4*)d_q.d, d_hits.d, (const uint32_t*)d_def.d, (const WfCounters*)d_ctr.d, (DevCounters*)nullptr);
+            HIP_CHECK(hipGetLastError());
+        }
+        HIP_CHECK(hipDeviceSynchronize());
+        std::vector<uint4> h((size_t)cap * 2);
+        d_hits.fetch(h.data(), h.size());
+        const uint32_t* word = (const uint32_t*)h.data();
+        const uint4* rest = (const uint4*)(word + cap);
+        for (uint64_t i = 0; i < n; ++i) {
+            pt_hit& o = out[i];
+            if (word[i] == 0xffffffffu) {
+                o.prim = -1;
+                o.flags = 0;
+                o.dist = o.u = o.v = 0.f;
+                continue;
+            }
+            const bool sphere = (word[i] & PT_PRIM_SPHERE) != 0;
+            o.prim = (int32_t)(word[i] & 0x0fffffffu);
+            o.flags = (int32_t)(((word[i] >> 30) & 1u) | (sphere ? 2u : 0u) | (((word[i] >> 29) & 1u) << 2));
+            memcpy(&o.dist, &rest[i].x, 4);
+            memcpy(&o.u, &rest[i].y, 4);
+            memcpy(&o.v, &rest[i].z, 4);
+            if (sphere) o.u = o.v = 0.f;
+        }
     });
 }
 

@@ -33,8 +33,17 @@ struct RawHit {
     uint32_t flags;  // bit0 backface, bit1 sphere, bit2 sphere exit
 };
 
-// Relative / absolute slack of the front-to-back early exit (kd_build.cpp, robustness rules).
-#define PT_EXIT_REL 1.00001f
+// Relative / absolute slack of the walk along the ray (kd_build.cpp, robustness rules): both children are visited when
+// the plane parameter lies within it of the node's interval, and the walk goes on while the next segment starts within it
+// of the best hit.  What it has to cover: Triangle::intersect in f32 accepts rays that pass a triangle's edge on the
+// OUTSIDE by s ~ 5 ... 50 x 2^-24 of the ray's length; when that edge lies in a split plane (the triangle lives on ONE side of
+// it) the ray point of the hit is on the wrong side and reaches the triangle's side only s / |d_axis| later along the ray.
+// 1e-5 (rounds 1-2) left rays with |d_axis| < 0.03 exposed: the grid-vs-KD check on config 5 found one in 2e10 casts
+// (profiles/r03_experiments.txt item 3).  1e-4 covers |d_axis| > 3e-3 for the same slop and costs 0.4 % of the frame
+// (1e-3: 2.1 %); fattening the primitives in the builder instead (PT_KD_PAD=1) closes the rest as well but costs 4-9 %.
+#ifndef PT_EXIT_REL
+#define PT_EXIT_REL 1.0001f
+#endif
 #define PT_EXIT_ABS 1e-6f
 
 // ---------------------------------------------------------------------------
@@ -98,7 +107,10 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
                 st_tmax[sp] = tmax;
                 ++sp;
                 node = first;
-                tmax = tplane;
+                // (never beyond the node's own interval: a plane within the slack PAST tmax must not inflate the near
+                // child's interval - nested, that compounds, the start reported for a later segment overtakes segments
+                // still on the stack, and the early exit below drops them: profiles/r03_experiments.txt item 3)
+                tmax = tplane < tmax ? tplane : tmax;
             }
             continue;
         }
@@ -220,7 +232,7 @@ PT_D bool next_hit(const DevScene& S, f3 o, f3 d, float t_prev, uint32_t ord_pre
     best.pid = 0xffffffffu;
     float dlen = mag3(d);
     float key_scale = dlen < 1.0f ? dlen : 1.0f;              // key >= t * min(1, |d|)
-    float t_start = t_prev > 0.f ? t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f) * 0.99999f - 1e-6f : 0.f;
+    float t_start = t_prev > 0.f ? t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f) * (2.f - PT_EXIT_REL) - PT_EXIT_ABS : 0.f;
     if (!(t_start > 0.f)) t_start = 0.f;
     float limit = INFINITY;
     kd_traverse<COUNT>(S, o, d, t_start, key_scale, limit, lc, [&](uint32_t first, uint32_t n) {

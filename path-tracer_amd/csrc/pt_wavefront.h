@@ -386,7 +386,7 @@ PT_D bool trav_enter(const DevScene& S, Trav& T, const TravStack& st, f3 o, f3 d
                 if (push) {
                     stack_push(st, sp, last_far, tmax);
                     ++sp;
-                    tmax = tplane;
+                    tmax = fminf(tplane, tmax);
                 }
             }
         }
@@ -450,7 +450,7 @@ PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float l
         if (both) {
             stack_push(st, T.sp, second, T.tmax);
             ++T.sp;
-            T.tmax = tplane;
+            T.tmax = fminf(tplane, T.tmax);   // (never beyond the node's own interval: see kd_traverse)
         }
         T.node = only_second ? second : first;
         return WF_LANE_WALK;
@@ -534,7 +534,7 @@ PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_pre
 
 PT_D float next_start(float t_prev, f3 d) {  // where a continuation cast may start (see next_hit)
     float dlen = mag3(d);
-    float t_start = t_prev > 0.f ? t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f) * 0.99999f - 1e-6f : 0.f;
+    float t_start = t_prev > 0.f ? t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f) * (2.f - PT_EXIT_REL) - PT_EXIT_ABS : 0.f;
     return t_start > 0.f ? t_start : 0.f;
 }
 

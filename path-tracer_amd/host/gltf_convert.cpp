@@ -430,8 +430,6 @@ struct Converter {
             if (!range_fits(off, len, doc.buffers[(size_t)bi].size())) fail(PT_ERR_PARSE, "glTF: image reaches beyond its buffer");
             bytes.assign(doc.buffers[(size_t)bi].begin() + off, doc.buffers[(size_t)bi].begin() + off + len);
         }
-        if (bytes.size() >= 3 && bytes[0] == 0xff && bytes[1] == 0xd8)
-            fail(PT_ERR_UNSUPPORTED, "glTF: image %lld is a JPEG; only PNG textures can be converted in this build", (long long)src);
         Image out;
         uint8_t* px = nullptr;
         if (pth_png_decode(bytes.data(), bytes.size(), 4, &out.w, &out.h, &px) != PT_OK)

@@ -68,7 +68,9 @@ struct PrimGeom {
 // Bounds of (triangle ∩ box), Sutherland–Hodgman in double precision against a box grown by a
 // relative epsilon (so a triangle that only touches the box is kept), rounded outward to f32 and
 // clamped to `box` and to the triangle's own AABB.  Returns false when the triangle misses the box.
-static bool clip_triangle_bounds(const PrimGeom& g, const Box& tri_box, const Box& box, Box& out) {
+// `pad`: the primitive is FATTENED by pad[a] along axis a (see kd_build: the slop of the f32 Möller–Trumbore test): the
+// clip planes move out by it and so do the resulting bounds (a box around (triangle + cube of half-edge pad) ∩ box).
+static bool clip_triangle_bounds(const PrimGeom& g, const Box& tri_box, const Box& box, const float* pad, Box& out) {
     double poly[2][16][3];
     int n = 3, cur = 0;
     for (int i = 0; i < 3; ++i)
@@ -76,7 +78,7 @@ static bool clip_triangle_bounds(const PrimGeom& g, const Box& tri_box, const Bo
     for (int a = 0; a < 3 && n > 0; ++a) {
         for (int side = 0; side < 2 && n > 0; ++side) {
             double scale = std::max(std::fabs((double)box.mn[a]), std::fabs((double)box.mx[a]));
-            double eps = 1e-6 * scale + 1e-9;
+            double eps = 1e-6 * scale + 1e-9 + (double)pad[a];
             double plane = side == 0 ? (double)box.mn[a] - eps : (double)box.mx[a] + eps;
             int m = 0;
             double(*in)[3] = poly[cur];
@@ -108,6 +110,8 @@ static bool clip_triangle_bounds(const PrimGeom& g, const Box& tri_box, const Bo
             lo = std::min(lo, poly[cur][i][a]);
             hi = std::max(hi, poly[cur][i][a]);
         }
+        lo -= (double)pad[a];
+        hi += (double)pad[a];
         float flo = (float)lo, fhi = (float)hi;
         if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
         if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
@@ -122,8 +126,9 @@ static bool clip_triangle_bounds(const PrimGeom& g, const Box& tri_box, const Bo
 }
 
 struct Builder {
-    const std::vector<Box>& boxes;
+    const std::vector<Box>& boxes;      // fattened (see kd_build)
     const std::vector<PrimGeom>& geom;
+    const std::vector<float>& pads;     // 3 per primitive
     float isect_cost;
     float trav_cost = 1.0f;
     float empty_bonus = 0.5f;
@@ -250,7 +255,7 @@ struct Builder {
                 const Box& child = side == 0 ? bb : ab;
                 Box c;
                 if (geom[p].is_tri && clip) {
-                    if (!clip_triangle_bounds(geom[p], boxes[p], child, c)) continue;  // misses this child
+                    if (!clip_triangle_bounds(geom[p], boxes[p], child, &pads[(size_t)p * 3], c)) continue;  // misses this child
                 } else {
                     for (int a = 0; a < 3; ++a) {
                         c.mn[a] = std::max(cb[i].mn[a], child.mn[a]);
@@ -344,6 +349,28 @@ static void kd_build(const pt_scene_desc& d, pth_kdtree& out) {
     prim_boxes(d, boxes);
     size_t n = boxes.size();
     if (n >= (1u << 30)) fail(PT_ERR_UNSUPPORTED, "too many primitives for the KD-tree (%zu)", n);
+    // Fattened primitives.  Triangle::intersect in f32 accepts rays that pass a triangle's edge on the OUTSIDE by a few
+    // 1e-6 of the ray's length (u + v comes out just under 1): with exact primitive bounds the ray point at such a hit
+    // can lie in a leaf that does not reference the triangle - e.g. beyond the split plane an axis-aligned edge sits in -
+    // and the walk's slack along the ray (1e-5 relative) does not reach far enough when the ray runs nearly parallel
+    // to that plane.  Found by the grid-vs-KD check on config 5 (4 M triangles, 8.5 G samples: one ray; the origin
+    // grids, whose margins come from a rounding analysis of the test, had it right).  So every primitive is entered
+    // into the tree with its bounds grown by the padding the oracle's candidate filter uses, 1e-4 |coordinate| + 1e-5
+    // per axis (oracle/pt_oracle.cpp prim_box): both filters then see the same fattened primitives.  PT_KD_PAD scales
+    // it.  MEASURED (profiles/r03_experiments.txt item 3): any non-zero padding ends the "a primitive that only touches
+    // a split plane stays on one side" economy at shared mesh edges - +45 % nodes, +43 % leaf references, +10 % node
+    // visits per ray - and costs 4 % of the frame on config 3, 9 % in the closed room.  The default is therefore 0 (exact
+    // bounds), with the walk's slack along the ray raised from 1e-5 to 1e-3 instead (PT_EXIT_REL, csrc/pt_integrator.h),
+    // which covers the case found and all but rays within 0.02 degrees of a split plane.
+    const float pad_scale = env_float("PT_KD_PAD", 0.f);
+    std::vector<float> pads(n * 3);
+    for (size_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const float pad = pad_scale * (1e-4f * std::max(fabsf(boxes[i].mn[a]), fabsf(boxes[i].mx[a])) + 1e-5f);
+            pads[i * 3 + a] = pad == pad ? pad : 0.f;
+            boxes[i].mn[a] -= pads[i * 3 + a];
+            boxes[i].mx[a] += pads[i * 3 + a];
+        }
     Box root;
     for (int a = 0; a < 3; ++a) {
         root.mn[a] = INFINITY;
@@ -376,7 +403,7 @@ static void kd_build(const pt_scene_desc& d, pth_kdtree& out) {
             }
         }
     }
-    Builder b{boxes, geom, env_float("PT_KD_ISECT_COST", 24.f), 1.0f, 0.5f, 2, 4, 64, true};
+    Builder b{boxes, geom, pads, env_float("PT_KD_ISECT_COST", 24.f), 1.0f, 0.5f, 2, 4, 64, true};
     b.clip = env_float("PT_KD_CLIP", 1.f) != 0.f;
     b.max_leaf = (uint32_t)env_float("PT_KD_MAX_LEAF", 4.f);
     b.par_levels = (int)env_float("PT_KD_PAR_LEVELS", 4.f);

@@ -1,4 +1,5 @@
-// Minimal PNG codec on top of zlib (libpng is not in the image).
+// Minimal PNG codec on top of zlib (libpng is not in the image); pth_png_read / pth_png_decode also take JPEG files
+// (sniffed by content, decoded by jpeg_codec.cpp): `image::open` decodes whatever format a texture comes in.
 //
 // Stands in for the `image` crate calls of the reference:
 //   image::open(path).into_rgb8()  / .into_luma8()   src/scene/internal/texture_bank.rs:33,49
@@ -22,6 +23,7 @@
 #include "host_common.hpp"
 
 namespace pth {
+void decode_jpeg(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32_t* oh, uint8_t** opx);   // jpeg_codec.cpp
 namespace {
 
 uint32_t be32(const uint8_t* p) {
@@ -39,7 +41,11 @@ uint8_t paeth(int a, int b, int c) {
 void decode(const uint8_t* data, size_t len, uint32_t want, uint32_t* ow, uint32_t* oh,
             uint8_t** opx) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
-    if (len < 8 || memcmp(data, sig, 8) != 0) fail(PT_ERR_PARSE, "not a PNG file");
+    if (len >= 3 && data[0] == 0xff && data[1] == 0xd8 && data[2] == 0xff) {   // a JPEG: the other format textures come in
+        decode_jpeg(data, len, want, ow, oh, opx);                             // (host/jpeg_codec.cpp)
+        return;
+    }
+    if (len < 8 || memcmp(data, sig, 8) != 0) fail(PT_ERR_PARSE, "not a PNG or JPEG file");
     if (want != 1 && want != 3 && want != 4) fail(PT_ERR_INVALID, "want_channels must be 1, 3 or 4");
     size_t pos = 8;
     uint32_t w = 0, h = 0;

@@ -91,6 +91,20 @@ def test_ray_cast_matches_oracle(pta, oracle, scene_cache, gpu_scene_cache, name
     g_first = gpu_scene_cache(name).trace(rays)
     assert np.array_equal(g_first["prim"], o_hits["prim"][:, 0])
     assert np.array_equal(bits(g_first["dist"]), bits(o_hits["dist"][:, 0]))
+    # ... and so does the wavefront integrator's own cast kernel (k_wf_trace: persistent lanes, resumable walk, LDS stack
+    # and tree top) - plain, with every cast handed to the cooperative kernel k_wf_trace_wide, and started at the home
+    # node of the primitive the ray leaves (entry lists; the secondary rays start on their first hit's primitive)
+    n_primary = 3000
+    start = np.zeros(len(rays), np.uint32)
+    start[n_primary:] = first["prim"][hit, 0]
+    for mode in (0, 2, 1, 3):
+        w = gpu_scene_cache(name).trace_wavefront(rays if mode & 1 == 0 else rays[n_primary:],
+                                                  None if mode & 1 == 0 else start[n_primary:], mode)
+        ref = o_hits if mode & 1 == 0 else o_hits[n_primary:]
+        assert np.array_equal(w["prim"], ref["prim"][:, 0]), mode
+        for f in ("dist", "u", "v"):
+            assert np.array_equal(bits(w[f]), bits(ref[f][:, 0])), (mode, f)
+        assert np.array_equal(w["flags"], ref["flags"][:, 0]), mode
 
 
 def gpu_math(pta, fn, x):
@@ -671,6 +685,23 @@ def test_config5_full_size(pta, oracle):
     idx = pta.local_pixel_map(prof, opts)
     r_rgb, r_acc = g.render(prof, opts)
     assert np.array_equal(bits(r_acc), bits(acc[idx])) and np.array_equal(r_rgb, rgb[idx])
+    # Two camera rays of this frame that the round-2 KD walk got wrong (found by the cross-check below):
+    # (a) sample 715 of pixel (2063, 1507) passes the axis-aligned edge x = 0.46 of triangle 3997384 on the OUTSIDE by
+    # 2e-6, f32 Möller–Trumbore accepts it, the triangle lives on the other side of the split plane x = 0.46 and the
+    # ray, nearly parallel to that plane, crosses it 1e-5 of its length later; (b) a ray of pixel (2206, 382) whose first
+    # hit was dropped by the early exit once the walk's slack was raised, until intervals stopped inflating past their
+    # node's own end.  Both through every cast implementation.
+    edge_rays = np.array([[0.6000000238418579, 2.4000000953674316, 9.0, -0.01791434735059738, -0.19532376527786255, -0.9805752038955688],
+                          [0.6000000238418579, 2.4000000953674316, 9.0, 0.027077317237854004, 0.17149730026721954, -0.9848123788833618]],
+                         np.float32)
+    o_list, o_n = oracle.OracleScene(scene.desc, oracle.PTO_BVH).trace_all(edge_rays, 8)
+    assert o_list["prim"][:, 0].tolist() == [3997384, 3987685]
+    g_list, g_n = g.trace_all(edge_rays, 8)
+    assert np.array_equal(g_n, o_n) and np.array_equal(g_list["prim"], o_list["prim"]) and \
+        np.array_equal(bits(g_list["dist"]), bits(o_list["dist"]))
+    for mode in (0, 2):
+        w = g.trace_wavefront(edge_rays, None, mode)
+        assert np.array_equal(w["prim"], o_list["prim"][:, 0]) and np.array_equal(bits(w["dist"]), bits(o_list["dist"][:, 0])), mode
     # the 8192^2 origin grids against the KD-tree (the grids' conservativeness is a rounding ANALYSIS,
     # host/origin_grid.cpp: this is its widest empirical net) and against the megakernel, one shard each
     for rank, f in ((5, pta.PT_FLAG_NO_GRIDS), (7, pta.PT_FLAG_MEGAKERNEL)):
