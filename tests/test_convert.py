@@ -24,7 +24,15 @@ def png_rgba(w, h, fn):
             chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
 
 
-def build_gltf(embed_png):
+def jpeg_bytes(w, h, fn, **kw):
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(np.array([[fn(x, y) for x in range(w)] for y in range(h)], np.uint8)).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def build_gltf(embed_png, jpeg=False):
     """One quad (indexed, u16) under a translated + scaled node, one non-indexed triangle under a rotated child,
     a perspective camera, a point / a spot / a directional light."""
     quad_pos = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
@@ -46,11 +54,14 @@ def build_gltf(embed_png):
     base = png_rgba(4, 2, lambda x, y: (10 * x, 100 + y, 200, 50 * x + y))          # rgb -> albedo, a -> alpha
     mr = png_rgba(2, 2, lambda x, y: (9, 40 + x, 80 + y, 255))                      # g -> roughness, b -> metalness
     nrm = png_rgba(2, 2, lambda x, y: (128, 128, 255, 255))
+    if jpeg:   # what real assets ship: JPEG base colour (no alpha: opaque), progressive JPEG metallic-roughness
+        base = jpeg_bytes(16, 8, lambda x, y: (10 * x, 100 + 8 * y, 200 - 5 * x), quality=90, subsampling=2)
+        mr = jpeg_bytes(8, 8, lambda x, y: (9, 40 + 20 * x, 80 + 10 * y), quality=95, progressive=True)
     images = []
     extra = {}
-    for name, data in (("base.png", base), ("mr.png", mr), ("n.png", nrm)):
+    for name, data in (("base.jpg" if jpeg else "base.png", base), ("mr.jpg" if jpeg else "mr.png", mr), ("n.png", nrm)):
         if embed_png:
-            images.append({"bufferView": view(data), "mimeType": "image/png"})
+            images.append({"bufferView": view(data), "mimeType": "image/jpeg" if data[:2] == b"\xff\xd8" else "image/png"})
         else:
             images.append({"uri": name})
             extra[name] = data
@@ -157,6 +168,70 @@ def test_convert_gltf_with_external_files(pta, oracle, tmp_path):
     scene = check_isf(pta, out)
     rgb, acc, st = oracle.OracleScene(scene.desc, oracle.PTO_BVH).render(pta.Profile.make(48, 32, 2, 2))
     assert st["numeric_errors"] == 0 and rgb.any()
+
+
+def write_jpeg_gltf(tmp_path):
+    doc, blob, extra = build_gltf(embed_png=False, jpeg=True)
+    doc["buffers"] = [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}]
+    src = tmp_path / "in"
+    src.mkdir()
+    (src / "scene.gltf").write_text(json.dumps(doc))
+    for name, data in extra.items():
+        (src / name).write_bytes(data)
+    return src / "scene.gltf", extra
+
+
+def test_convert_gltf_with_jpeg_textures(pta, oracle, tmp_path):
+    """JPEG images (gltf.rs:27-45 goes through easy-gltf / image, which decode them): the textures written are the
+    decoded pixels, PIL's decode being the yardstick; a JPEG has no alpha, so the alpha texture is all 255."""
+    import io
+    from PIL import Image
+    gltf, extra = write_jpeg_gltf(tmp_path)
+    out = tmp_path / "out"
+    pta.convert_gltf(gltf, out)
+    isf = json.loads((out / "scene.isf").read_text())
+    m = isf["models"][0]["material"]
+    albedo = np.asarray(Image.open(out / m["albedo"]["texture"]).convert("RGB"))
+    assert np.array_equal(albedo, np.asarray(Image.open(io.BytesIO(extra["base.jpg"])).convert("RGB")))
+    assert (np.asarray(Image.open(out / m["opacity"]["texture"]).convert("L")) == 255).all()
+    mr = np.asarray(Image.open(io.BytesIO(extra["mr.jpg"])).convert("RGB"))
+    assert np.array_equal(np.asarray(Image.open(out / m["metalness"]["texture"]).convert("L")), mr[..., 2])     # blue -> metalness
+    assert np.array_equal(np.asarray(Image.open(out / m["roughness"]["texture"]).convert("L")), mr[..., 1])     # green -> roughness
+    scene = pta.HostScene.load_isf(out / "scene.isf")
+    rgb, _, st = oracle.OracleScene(scene.desc, oracle.PTO_BVH).render(pta.Profile.make(48, 32, 2, 2))
+    assert st["numeric_errors"] == 0 and rgb.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jpeg", [False, True])
+def test_converted_scene_renders_like_the_oracle(pta, oracle, tmp_path, jpeg):
+    """convert -> load -> render on the MI355X: image and f32 accumulation equal the oracle's bit for bit, on the
+    grid path, the KD-only path and the megakernel; the G-buffer planes too."""
+    if jpeg:
+        gltf, _ = write_jpeg_gltf(tmp_path)
+    else:
+        doc, blob, extra = build_gltf(embed_png=False)
+        doc["buffers"] = [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}]
+        (tmp_path / "in").mkdir()
+        gltf = tmp_path / "in" / "scene.gltf"
+        gltf.write_text(json.dumps(doc))
+        for name, data in extra.items():
+            (tmp_path / "in" / name).write_bytes(data)
+    out = tmp_path / "out"
+    pta.convert_gltf(gltf, out)
+    scene = pta.HostScene.load_isf(out / "scene.isf")
+    g = pta.GpuScene(scene)
+    prof = pta.Profile.make(192, 128, 8, 4)
+    o_rgb, o_acc, st = oracle.OracleScene(scene.desc, oracle.PTO_BVH).render(prof)
+    assert st["numeric_errors"] == 0
+    for flags in (0, pta.PT_FLAG_NO_GRIDS, pta.PT_FLAG_MEGAKERNEL):
+        rgb, acc = g.render(prof, pta.Opts.make(flags=flags))
+        assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(rgb, o_rgb), flags
+    assert len(np.unique(o_rgb.reshape(-1, 3), axis=0)) > 50
+    got = g.debug_render(192, 128)
+    ref = oracle.OracleScene(scene.desc, oracle.PTO_BVH).debug_render(192, 128)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
 
 
 def test_convert_glb_through_the_cli(pta, tmp_path):

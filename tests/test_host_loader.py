@@ -174,6 +174,104 @@ def test_png_trns_becomes_alpha(pta, tmp_path):
         assert (got[..., 3] < 255).any() and (got[..., 3] > 0).any(), name
 
 
+def test_jpeg_decode_matches_libjpeg(pta):
+    """JPEG textures (`image::open` decodes them for the reference: ISF textures, texture_bank.rs:33,49, and the images
+    of a glTF file, gltf.rs:27-45).  A JPEG decode is only specified up to the accuracy of the inverse DCT, so the
+    yardstick is the decoder everybody ships: PIL's libjpeg-turbo with its defaults (slow-integer IDCT, fancy chroma
+    upsampling) - bit for bit, baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0 / greyscale, odd sizes, into rgb, rgba
+    and luma."""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    lib = pta.host_lib()
+
+    def decode(data, want):
+        w, h, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+        pta.check_host(lib.pth_png_decode(data, len(data), want, C.byref(w), C.byref(h), C.byref(px)))
+        a = np.ctypeslib.as_array(px, (h.value, w.value, want)).copy()
+        lib.pth_free(px)
+        return a
+    n = 0
+    for (W, H) in ((64, 48), (37, 29), (8, 8), (1, 1), (17, 3), (130, 75)):
+        y, x = np.mgrid[0:H, 0:W]
+        img = np.stack([(x * 4 + y * 2) % 256, (y * 5) % 256, (x * y) % 256], -1)
+        img = (img // 2 + rng.integers(0, 128, (H, W, 3))).astype(np.uint8)
+        for mode in ("RGB", "L"):
+            im = Image.fromarray(img).convert(mode)
+            for sub in ((0, 1, 2) if mode == "RGB" else (0,)):
+                for prog in (False, True):
+                    for q in (30, 90):
+                        b = io.BytesIO()
+                        kw = dict(quality=q, progressive=prog)
+                        if mode == "RGB":
+                            kw["subsampling"] = sub
+                        im.save(b, "JPEG", **kw)
+                        data = b.getvalue()
+                        ref = Image.open(io.BytesIO(data))
+                        assert np.array_equal(decode(data, 3), np.asarray(ref.convert("RGB"))), (W, H, mode, sub, prog, q)
+                        n += 1
+    assert n == 96
+    # rgba: opaque; luma of a greyscale file: the samples themselves; of a colour file: the integer weights of png_codec
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", quality=80)
+    rgba = decode(b.getvalue(), 4)
+    assert (rgba[..., 3] == 255).all() and np.array_equal(rgba[..., :3], decode(b.getvalue(), 3))
+    rgb = decode(b.getvalue(), 3).astype(np.uint32)
+    assert np.array_equal(decode(b.getvalue(), 1)[..., 0], (2126 * rgb[..., 0] + 7152 * rgb[..., 1] + 722 * rgb[..., 2]) // 10000)
+    b = io.BytesIO()
+    Image.fromarray(img).convert("L").save(b, "JPEG", quality=80)
+    assert np.array_equal(decode(b.getvalue(), 1)[..., 0], np.asarray(Image.open(io.BytesIO(b.getvalue()))))
+
+
+def test_jpeg_errors_are_errors(pta):
+    """Truncated, damaged and unsupported files: an error code and a message, never a crash."""
+    import io
+    from PIL import Image
+    lib = pta.host_lib()
+    b = io.BytesIO()
+    Image.fromarray(np.arange(64 * 64 * 3, dtype=np.uint8).reshape(64, 64, 3)).save(b, "JPEG", quality=85)
+    good = b.getvalue()
+    w, h, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+
+    def rc(data):
+        r = lib.pth_png_decode(data, len(data), 3, C.byref(w), C.byref(h), C.byref(px))
+        if r == 0:
+            lib.pth_free(px)
+        return r
+    assert rc(good) == 0
+    assert rc(good[:20]) != 0 and b"JPEG" in lib.pth_last_error()
+    assert rc(good[:2] + b"\xff\xc9" + good[4:]) != 0                       # arithmetic coding (SOF9) in place of APP0
+    sof = good.index(b"\xff\xc0")
+    assert rc(good[:sof + 4] + b"\x0c" + good[sof + 5:]) != 0 and b"12-bit" in lib.pth_last_error()
+    assert rc(good[:sof + 5] + b"\xff\xff\xff\xff" + good[sof + 9:]) != 0   # 65535 x 65535 pixels claimed by a 1 KB file
+    rng = np.random.default_rng(3)
+    for _ in range(300):   # random damage decodes to something or fails cleanly
+        d = bytearray(good)
+        for k in rng.integers(2, len(d), 6):
+            d[k] = rng.integers(0, 256)
+        rc(bytes(d))
+
+
+def test_isf_scene_with_a_jpeg_texture(pta, oracle, tmp_path):
+    """An ISF material may name a .jpg (texture_bank.rs:33: image::open decodes whatever it finds)."""
+    import json
+    from PIL import Image
+    img = (np.indices((16, 16)).sum(0) * 8 % 256).astype(np.uint8)
+    Image.fromarray(np.stack([img, 255 - img, img // 2], -1)).save(tmp_path / "wood.jpg", quality=92)
+    tri = [{"position": p, "normal": [0, 0, 1], "tex_coords": uv} for p, uv in (([-1, -1, 0], [0, 0]), ([1, -1, 0], [1, 0]), ([0, 1, 0], [0.5, 1]))]
+    doc = {"models": [{"type": "Mesh", "triangles": [tri], "material": {"albedo": {"texture": "wood.jpg"}}}],
+           "camera": {"transform": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 3, 1]], "fov": 0.8, "zfar": 100.0, "znear": 0.1},
+           "lights": [{"type": "Point", "position": [0, 0, 2], "color": [30, 30, 30], "size": 0.1}], "background": [0.1, 0.1, 0.1]}
+    (tmp_path / "scene.isf").write_text(json.dumps(doc))
+    scene = pta.HostScene.load_isf(tmp_path / "scene.isf")
+    d = scene.desc.contents
+    assert d.n_textures == 1 and d.textures[0].width == 16 and d.textures[0].channels == 3
+    texels = np.ctypeslib.as_array(d.texels, (d.n_texel_bytes,))[:16 * 16 * 3].reshape(16, 16, 3)
+    assert np.array_equal(texels, np.asarray(Image.open(tmp_path / "wood.jpg").convert("RGB")))
+    rgb, _, st = oracle.OracleScene(scene.desc, oracle.PTO_BVH).render(pta.Profile.make(32, 24, 2, 1))
+    assert st["numeric_errors"] == 0 and len(np.unique(rgb.reshape(-1, 3), axis=0)) > 10
+
+
 def test_texture_cache_and_sharing(pta, tmp_path):
     from PIL import Image
     Image.fromarray(np.full((4, 4, 3), 200, np.uint8)).save(tmp_path / "t.png")
