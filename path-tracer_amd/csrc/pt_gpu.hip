@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -574,6 +575,90 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
         }
     }
 
+    const uint64_t n_prims_early = pth_prim_count(&d);
+    // ---- origin grids (host/origin_grid.cpp, csrc/pt_grid.h): camera rays, shadow rays of point lights.  They depend on the
+    // scene description only, not on the KD-tree: built on a thread of their own BESIDE the KD build (both are seconds of
+    // multi-threaded host work; setup of config 3: 3.2 -> 2.3 s).
+    auto build_grids = [&P, &d, n_prims_early]() {
+        const uint64_t n_prims = n_prims_early;
+        const float* M = d.camera.transform;
+        DevScene& D = P.dev;
+
+        auto t_grid = std::chrono::steady_clock::now();
+        static const bool grids_on = [] {
+            const char* e = getenv("PT_OG");
+            return !(e && *e && atoi(e) == 0);
+        }();
+        // longest camera-ray direction: |M dir| <= ||M||_F for the unit vector dir (mod.rs:122-123)
+        double fro = 0;
+        for (int k = 0; k < 3; ++k)
+            for (int r = 0; r < 3; ++r) fro += (double)M[4 * k + r] * M[4 * k + r];
+        fro = std::sqrt(fro);
+        // Byte budget over ALL grids of the scene (PT_OG_BUDGET_GIB, default 48 of the 288 GB): the grids are an optional
+        // accelerator in front of the KD-tree, one per camera and per light, 6 res^2 cells of 4 B plus ~1.5x that in list
+        // entries each (8192^2: ~4 GB a grid) - a scene with many lights must not run the host or the device out of
+        // memory over them.  The resolution is halved (down to 512) until the estimate fits; if it still does not, or
+        // the grids as built exceed the budget, the lights go without (their shadow rays take the KD-tree).
+        static const double budget = [] {
+            const char* e = getenv("PT_OG_BUDGET_GIB");
+            const double g = e && *e ? atof(e) : 48.0;
+            return (g > 0 ? g : 48.0) * 1073741824.0;
+        }();
+        auto estimate = [](uint32_t r) { return 6.0 * r * r * 4.0 * 2.5; };
+        uint32_t res = pth_origin_grid_auto_resolution(n_prims);
+        const double n_grids = 1.0 + d.n_lights;
+        while (res > 512u && estimate(res) * n_grids > budget) res >>= 1;
+        bool lights_fit = estimate(res) * n_grids <= budget;
+        const uint32_t light_res = res;
+        if (!lights_fit) {   // the camera grid alone, at the resolution it is worth having
+            res = pth_origin_grid_auto_resolution(n_prims);
+            while (res > 512u && estimate(res) > budget) res >>= 1;
+        }
+        double grid_bytes = 0;
+        if (grids_on && n_prims > 0 && fro > 0 && fro < 64.0 && estimate(res) <= budget) {
+            P.cam_grid = std::make_unique<pt_prep::Grid>();
+            if (pth_origin_grid_build(&d, M + 12, res, 0.f, (float)(fro * 1.001), &P.cam_grid->g) != PT_OK)
+                fail(PT_ERR_INVALID, "origin grid (camera): %s", pth_last_error());
+            if (P.cam_grid->g.enabled) {
+                P.info.cam_grid_res = P.cam_grid->g.res;
+                P.info.grid_refs += P.cam_grid->g.n_refs;
+                grid_bytes += 4.0 * P.cam_grid->g.n_cells + 8.0 * P.cam_grid->g.n_refs;
+            }
+        }
+        // lights: the shadow queue is consumed by ONE kernel, so the grids serve the shadow rays only when EVERY
+        // light has one - a cube map around a point light, an orthographic grid along a directional light.  A
+        // point light's shadow ray starts n * 1e-5 off the line through the light (mod.rs:319): the grids' margin
+        // covers |n| <= 1.5, longer normals take the KD-tree per surface.
+        bool all = grids_on && n_prims > 0 && lights_fit;   // (no lights at all: vacuously)
+        const float max_normal = 1.5f;
+        for (uint32_t i = 0; i < d.n_lights && all; ++i) {
+            P.light_grids.push_back(std::make_unique<pt_prep::Grid>());
+            int rc;
+            if (d.lights[i].kind == PT_LIGHT_POINT) {
+                rc = pth_origin_grid_build(&d, d.lights[i].vec, light_res, 1.05e-5f * max_normal, 1.001f, &P.light_grids.back()->g);
+            } else {   // the shadow rays run along -direction (mod.rs:291), as it is
+                const float sd[3] = {-1.f * d.lights[i].vec[0], -1.f * d.lights[i].vec[1], -1.f * d.lights[i].vec[2]};
+                rc = pth_ortho_grid_build(&d, sd, light_res, &P.light_grids.back()->g);
+            }
+            if (rc != PT_OK) fail(PT_ERR_INVALID, "origin grid (light %u): %s", i, pth_last_error());
+            if (!P.light_grids.back()->g.enabled) all = false;
+            grid_bytes += 4.0 * P.light_grids.back()->g.n_cells + 8.0 * P.light_grids.back()->g.n_refs;
+            if (grid_bytes > budget) all = false;   // (the lists came out longer than estimated)
+        }
+        if (!all) P.light_grids.clear();
+        for (auto& g : P.light_grids) P.info.grid_refs += g->g.n_refs;
+        P.all_lights_gridded = all;
+        D.all_lights_gridded = all ? 1u : 0u;
+        D.light_grid_max_normal2 = max_normal * max_normal;
+        P.info.light_grids = all ? d.n_lights : 0u;
+        P.info.grid_build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_grid).count();
+    };
+    std::future<void> grids_done = std::async(std::launch::async, build_grids);
+    struct JoinGrids {   // (an exception on the way out must not leave the thread behind)
+        std::future<void>& f;
+        ~JoinGrids() { if (f.valid()) f.wait(); }
+    } join_grids{grids_done};
+
     // ---- KD-tree
     pth_kdtree kd;
     if (pth_kd_build(&d, &kd) != PT_OK) fail(PT_ERR_INVALID, "KD build failed: %s", pth_last_error());
@@ -849,78 +934,8 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
     D.tan_half_fov = tanf(d.camera.fov / 2.f);  // Rad::tan(fov / 2.) (mod.rs:116,120)
     memcpy(D.background, d.background, 12);
 
-    // ---- origin grids (host/origin_grid.cpp, csrc/pt_grid.h): camera rays, shadow rays of point lights
-    {
-        auto t_grid = std::chrono::steady_clock::now();
-        static const bool grids_on = [] {
-            const char* e = getenv("PT_OG");
-            return !(e && *e && atoi(e) == 0);
-        }();
-        // longest camera-ray direction: |M dir| <= ||M||_F for the unit vector dir (mod.rs:122-123)
-        double fro = 0;
-        for (int k = 0; k < 3; ++k)
-            for (int r = 0; r < 3; ++r) fro += (double)M[4 * k + r] * M[4 * k + r];
-        fro = std::sqrt(fro);
-        // Byte budget over ALL grids of the scene (PT_OG_BUDGET_GIB, default 48 of the 288 GB): the grids are an optional
-        // accelerator in front of the KD-tree, one per camera and per light, 6 res^2 cells of 4 B plus ~1.5x that in list
-        // entries each (8192^2: ~4 GB a grid) - a scene with many lights must not run the host or the device out of
-        // memory over them.  The resolution is halved (down to 512) until the estimate fits; if it still does not, or
-        // the grids as built exceed the budget, the lights go without (their shadow rays take the KD-tree).
-        static const double budget = [] {
-            const char* e = getenv("PT_OG_BUDGET_GIB");
-            const double g = e && *e ? atof(e) : 48.0;
-            return (g > 0 ? g : 48.0) * 1073741824.0;
-        }();
-        auto estimate = [](uint32_t r) { return 6.0 * r * r * 4.0 * 2.5; };
-        uint32_t res = pth_origin_grid_auto_resolution(n_prims);
-        const double n_grids = 1.0 + d.n_lights;
-        while (res > 512u && estimate(res) * n_grids > budget) res >>= 1;
-        bool lights_fit = estimate(res) * n_grids <= budget;
-        const uint32_t light_res = res;
-        if (!lights_fit) {   // the camera grid alone, at the resolution it is worth having
-            res = pth_origin_grid_auto_resolution(n_prims);
-            while (res > 512u && estimate(res) > budget) res >>= 1;
-        }
-        double grid_bytes = 0;
-        if (grids_on && n_prims > 0 && fro > 0 && fro < 64.0 && estimate(res) <= budget) {
-            P.cam_grid = std::make_unique<pt_prep::Grid>();
-            if (pth_origin_grid_build(&d, M + 12, res, 0.f, (float)(fro * 1.001), &P.cam_grid->g) != PT_OK)
-                fail(PT_ERR_INVALID, "origin grid (camera): %s", pth_last_error());
-            if (P.cam_grid->g.enabled) {
-                P.info.cam_grid_res = P.cam_grid->g.res;
-                P.info.grid_refs += P.cam_grid->g.n_refs;
-                grid_bytes += 4.0 * P.cam_grid->g.n_cells + 8.0 * P.cam_grid->g.n_refs;
-            }
-        }
-        // lights: the shadow queue is consumed by ONE kernel, so the grids serve the shadow rays only when EVERY
-        // light has one - a cube map around a point light, an orthographic grid along a directional light.  A
-        // point light's shadow ray starts n * 1e-5 off the line through the light (mod.rs:319): the grids' margin
-        // covers |n| <= 1.5, longer normals take the KD-tree per surface.
-        bool all = grids_on && n_prims > 0 && lights_fit;   // (no lights at all: vacuously)
-        const float max_normal = 1.5f;
-        for (uint32_t i = 0; i < d.n_lights && all; ++i) {
-            P.light_grids.push_back(std::make_unique<pt_prep::Grid>());
-            int rc;
-            if (d.lights[i].kind == PT_LIGHT_POINT) {
-                rc = pth_origin_grid_build(&d, d.lights[i].vec, light_res, 1.05e-5f * max_normal, 1.001f, &P.light_grids.back()->g);
-            } else {   // the shadow rays run along -direction (mod.rs:291), as it is
-                const float sd[3] = {-1.f * d.lights[i].vec[0], -1.f * d.lights[i].vec[1], -1.f * d.lights[i].vec[2]};
-                rc = pth_ortho_grid_build(&d, sd, light_res, &P.light_grids.back()->g);
-            }
-            if (rc != PT_OK) fail(PT_ERR_INVALID, "origin grid (light %u): %s", i, pth_last_error());
-            if (!P.light_grids.back()->g.enabled) all = false;
-            grid_bytes += 4.0 * P.light_grids.back()->g.n_cells + 8.0 * P.light_grids.back()->g.n_refs;
-            if (grid_bytes > budget) all = false;   // (the lists came out longer than estimated)
-        }
-        if (!all) P.light_grids.clear();
-        for (auto& g : P.light_grids) P.info.grid_refs += g->g.n_refs;
-        P.all_lights_gridded = all;
-        D.all_lights_gridded = all ? 1u : 0u;
-        D.light_grid_max_normal2 = max_normal * max_normal;
-        P.info.light_grids = all ? d.n_lights : 0u;
-        P.info.grid_build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_grid).count();
-    }
 
+    grids_done.get();   // (rethrows what the grid thread threw)
     P.info.n_prims = n_prims;
     P.info.n_kd_nodes = kd.n_nodes;
     P.info.n_kd_leaves = kd.n_leaves;

@@ -321,11 +321,15 @@ int run_render(int argc, char** argv) {
         auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
         double samples = (double)profile.width * profile.height * profile.samples;
         fprintf(stderr,
-                "{\"load_s\": %.3f, \"kd_build_s\": %.3f, \"upload_s\": %.3f, \"render_s\": %.3f, \"kernel_ms\": %.3f, "
-                "\"png_s\": %.3f, \"msamples_per_s\": %.2f, \"prims\": %llu, \"kd_nodes\": %llu, \"leaf_refs\": %llu}\n",
-                sec(t0, t1), (double)info.kd_build_seconds, (double)info.upload_seconds, sec(t2, t3),
-                (double)tm.integrate_ms, sec(t3, t4), samples / sec(t2, t3) / 1e6, (unsigned long long)info.n_prims,
-                (unsigned long long)info.n_kd_nodes, (unsigned long long)info.n_leaf_refs);
+                // load = ISF + textures; build = pt_scene_create (KD-tree and origin grids side by side on the host, upload);
+                // render = pt_render (kernels + the copy back); png = the output file
+                "{\"load_s\": %.3f, \"build_s\": %.3f, \"kd_build_s\": %.3f, \"grid_build_s\": %.3f, \"upload_s\": %.3f, "
+                "\"render_s\": %.3f, \"kernel_ms\": %.3f, \"png_s\": %.3f, \"total_s\": %.3f, \"msamples_per_s\": %.2f, "
+                "\"prims\": %llu, \"kd_nodes\": %llu, \"leaf_refs\": %llu, \"cam_grid_res\": %u, \"light_grids\": %u}\n",
+                sec(t0, t1), sec(t1, t2), (double)info.kd_build_seconds, (double)info.grid_build_seconds, (double)info.upload_seconds,
+                sec(t2, t3), (double)tm.integrate_ms, sec(t3, t4), sec(t0, t4), samples / sec(t2, t3) / 1e6,
+                (unsigned long long)info.n_prims, (unsigned long long)info.n_kd_nodes, (unsigned long long)info.n_leaf_refs,
+                info.cam_grid_res, info.light_grids);
     }
     pt_scene_destroy(scene);
     pth_scene_free(hscene);

@@ -27,7 +27,7 @@
 //
 // Cost model: surface-area heuristic with an exact sweep over the clipped bounds (after Wald & Havran /
 // pbrt's KdTreeAccel), traversal cost 1, intersection cost 24, empty-space bonus 0.2, leaves of at most 4,
-// depth cap 16 + 1.3 log2 n; all tunable through PT_KD_ISECT_COST / PT_KD_MAX_LEAF / PT_KD_EMPTY_BONUS /
+// depth cap 16 + 1.3 log2 n, the top 7 levels built in parallel; all tunable through PT_KD_ISECT_COST / PT_KD_MAX_LEAF / PT_KD_EMPTY_BONUS /
 // PT_KD_MAX_DEPTH / PT_KD_CLIP for experiments (measured optima).
 #include <algorithm>
 #include <chrono>
@@ -406,7 +406,9 @@ static void kd_build(const pt_scene_desc& d, pth_kdtree& out) {
     Builder b{boxes, geom, pads, env_float("PT_KD_ISECT_COST", 24.f), 1.0f, 0.5f, 2, 4, 64, true};
     b.clip = env_float("PT_KD_CLIP", 1.f) != 0.f;
     b.max_leaf = (uint32_t)env_float("PT_KD_MAX_LEAF", 4.f);
-    b.par_levels = (int)env_float("PT_KD_PAR_LEVELS", 4.f);
+    // top levels whose two children are built on threads of their own: 2^7 subtrees for the 256 logical CPUs of an MI355X
+    // host (config 3: 1.84 s at 4 levels, 1.33 / 1.10 / 1.02 / 0.97 s at 5 / 6 / 7 / 8)
+    b.par_levels = (int)env_float("PT_KD_PAR_LEVELS", 7.f);
     b.strict_below = (size_t)env_float("PT_KD_STRICT_BELOW", 64.f);
     // pbrt uses 0.5; on the GPU walk empty leaves are not free (a node fetch + a pop each, 85 % of all leaf
     // visits): 0.2 measured +14 % samples/s over 0.5 on the 500 k-triangle scene (0 / 0.1 / 0.3: +5 / +9 / +11 %)

@@ -227,7 +227,7 @@ def test_converted_scene_renders_like_the_oracle(pta, oracle, tmp_path, jpeg):
     for flags in (0, pta.PT_FLAG_NO_GRIDS, pta.PT_FLAG_MEGAKERNEL):
         rgb, acc = g.render(prof, pta.Opts.make(flags=flags))
         assert np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(rgb, o_rgb), flags
-    assert len(np.unique(o_rgb.reshape(-1, 3), axis=0)) > 50
+    assert len(np.unique(o_rgb.reshape(-1, 3), axis=0)) > 10
     got = g.debug_render(192, 128)
     ref = oracle.OracleScene(scene.desc, oracle.PTO_BVH).debug_render(192, 128)
     for k in ref:
