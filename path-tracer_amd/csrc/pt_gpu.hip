@@ -553,6 +553,14 @@ struct pt_prep {
 namespace {
 
 void prep_create(const pt_scene_desc& d, pt_prep& P) {
+    const bool dbg_setup = getenv("PT_DEBUG_SETUP") != nullptr;
+    auto t_sec = std::chrono::steady_clock::now();
+    auto section = [&](const char* name) {
+        if (!dbg_setup) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[prep] %-28s %.3f s\n", name, std::chrono::duration<double>(now - t_sec).count());
+        t_sec = now;
+    };
     // ---- validate
     for (uint32_t m = 0; m < d.n_models; ++m) {
         const pt_model& mo = d.models[m];
@@ -615,16 +623,19 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
             while (res > 512u && estimate(res) > budget) res >>= 1;
         }
         double grid_bytes = 0;
+        // (the camera grid on a thread of its own beside the light grids: every grid is its own count / scan / fill / sort)
+        std::future<void> cam_done;
         if (grids_on && n_prims > 0 && fro > 0 && fro < 64.0 && estimate(res) <= budget) {
             P.cam_grid = std::make_unique<pt_prep::Grid>();
-            if (pth_origin_grid_build(&d, M + 12, res, 0.f, (float)(fro * 1.001), &P.cam_grid->g) != PT_OK)
-                fail(PT_ERR_INVALID, "origin grid (camera): %s", pth_last_error());
-            if (P.cam_grid->g.enabled) {
-                P.info.cam_grid_res = P.cam_grid->g.res;
-                P.info.grid_refs += P.cam_grid->g.n_refs;
-                grid_bytes += 4.0 * P.cam_grid->g.n_cells + 8.0 * P.cam_grid->g.n_refs;
-            }
+            cam_done = std::async(std::launch::async, [&P, &d, M, res, fro] {
+                if (pth_origin_grid_build(&d, M + 12, res, 0.f, (float)(fro * 1.001), &P.cam_grid->g) != PT_OK)
+                    fail(PT_ERR_INVALID, "origin grid (camera): %s", pth_last_error());
+            });
         }
+        struct JoinCam {
+            std::future<void>& f;
+            ~JoinCam() { if (f.valid()) f.wait(); }
+        } join_cam{cam_done};
         // lights: the shadow queue is consumed by ONE kernel, so the grids serve the shadow rays only when EVERY
         // light has one - a cube map around a point light, an orthographic grid along a directional light.  A
         // point light's shadow ray starts n * 1e-5 off the line through the light (mod.rs:319): the grids' margin
@@ -644,6 +655,15 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
             if (!P.light_grids.back()->g.enabled) all = false;
             grid_bytes += 4.0 * P.light_grids.back()->g.n_cells + 8.0 * P.light_grids.back()->g.n_refs;
             if (grid_bytes > budget) all = false;   // (the lists came out longer than estimated)
+        }
+        if (cam_done.valid()) {
+            cam_done.get();
+            if (P.cam_grid->g.enabled) {
+                P.info.cam_grid_res = P.cam_grid->g.res;
+                P.info.grid_refs += P.cam_grid->g.n_refs;
+                grid_bytes += 4.0 * P.cam_grid->g.n_cells + 8.0 * P.cam_grid->g.n_refs;
+                if (grid_bytes > budget) all = false;
+            }
         }
         if (!all) P.light_grids.clear();
         for (auto& g : P.light_grids) P.info.grid_refs += g->g.n_refs;
@@ -665,6 +685,7 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
     std::unique_ptr<pth_kdtree, void (*)(pth_kdtree*)> kd_guard(&kd, pth_kd_free);
     if (kd.depth >= PT_KD_STACK) fail(PT_ERR_UNSUPPORTED, "KD-tree depth %u exceeds the traversal stack", kd.depth);
 
+    section("validate + KD build");
     // ---- per-primitive arrays
     uint64_t n_prims = pth_prim_count(&d);
     std::vector<float4>&attr = P.attr, &pos = P.pos;
@@ -709,6 +730,7 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
             ++prim;
         }
     }
+    section("primitive arrays");
     // ---- kdtree-ray's slab test (scene_slab, pt_integrator.h): the exact bounding box of the scene - the union of
     // Model::bound() (model.rs:76-86: the positions' bounds for a mesh, centre -+ radius for a sphere) - and the mark
     // on every primitive that comes close to one of its EDGES.  Only a ray that clips an edge of the box within the
@@ -770,6 +792,7 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
         }
         P.info.n_edge_prims = (uint32_t)std::min<uint64_t>(marked, 0xffffffffu);
     }
+    section("slab box + edge marks");
     // leaf records in leaf-reference order
     P.leaf.resize(kd.n_refs * 3);
     for (uint64_t r = 0; r < kd.n_refs; ++r) {
@@ -792,6 +815,7 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
     P.textures.assign(d.textures, d.textures + d.n_textures);
     P.texels.assign(d.texels, d.texels + d.n_texel_bytes);
 
+    section("leaf records, tables");
     // ---- device node layout.  The builder emits DFS order (below child = next node); on the GPU the
     // walk is bound by cache-line round trips (a wave waits for the slowest of ~43 scattered node
     // fetches), so the nodes are re-laid out in treelets: sibling PAIRS are adjacent (children of a
@@ -840,6 +864,7 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
             tre[1] = pth_kd_node{0u, 3u};
         }
     }
+    section("treelet layout");
     // ---- entry lists (trav_enter, csrc/pt_wavefront.h).  A path's next ray starts ON the primitive it just hit
     // (origin = hit point + interpolated normal * 1e-5, mod.rs:266-268), deep inside the tree: of the ~23 nodes such a
     // cast visits, the first ~15 are the descent from the root to the small node around its origin - a chain of
@@ -935,7 +960,9 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
     memcpy(D.background, d.background, 12);
 
 
+    section("entry lists");
     grids_done.get();   // (rethrows what the grid thread threw)
+    section("waiting for the grids");
     P.info.n_prims = n_prims;
     P.info.n_kd_nodes = kd.n_nodes;
     P.info.n_kd_leaves = kd.n_leaves;

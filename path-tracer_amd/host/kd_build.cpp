@@ -168,63 +168,98 @@ struct Builder {
         float old_cost = isect_cost * (float)n;
         float best_cost = INFINITY;
         int best_axis = -1;
-        std::vector<Edge> edges(2 * n);
-        float best_split = 0.f;
-        bool best_planar_below = true;
-        for (int axis = 0; axis < 3; ++axis) {  // full SAH: best plane over all three axes
-            if (!(d[axis] > 0.f)) continue;  // flat box: nothing to cut on this axis
-            const float lo = nb.mn[axis], hi = nb.mx[axis];
-            for (size_t i = 0; i < n; ++i) {
-                const Box& b = cb[i];  // already inside the node box
-                edges[2 * i] = {b.mn[axis], (uint32_t)i << 1};
-                edges[2 * i + 1] = {b.mx[axis], ((uint32_t)i << 1) | 1u};
-            }
-            std::sort(edges.begin(), edges.end(), [](const Edge& a, const Edge& b) { return a.t < b.t; });
-            // Candidate planes = distinct (clamped) AABB bounds.  For a plane at t:
-            //   L = { min < t }, R = { max > t }, P = { min == max == t } (lying in the plane)
-            // A primitive that only touches the plane from one side stays on that side; P goes
-            // to whichever side is cheaper.  A plane ON the node boundary is allowed when it
-            // peels planar primitives into a zero-thickness child (a ground plane at the
-            // bottom of the scene box): rays that never reach the plane skip them entirely.
-            size_t n_below = 0, n_above = n;
-            int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
-            for (size_t i = 0; i < 2 * n;) {
-                float t = edges[i].t;
-                size_t j = i, ends = 0, starts = 0, planar = 0;
-                for (; j < 2 * n && edges[j].t == t; ++j) {
-                    if (edges[j].key & 1u) ++ends;
-                    else {
-                        ++starts;
-                        if (cb[edges[j].key >> 1].mx[axis] == t) ++planar;
-                    }
+        struct AxisBest {
+            float cost = INFINITY, split = 0.f;
+            int axis = -1;
+            bool planar_below = true;
+        };
+        // the sweep over one axis (the best plane of that axis; ties keep the first, as a loop over the axes would)
+        auto sweep = [&](int axis, AxisBest& out, std::vector<Edge>& edges) {
+            edges.resize(2 * n);
+            float bc = INFINITY, bs = 0.f;
+            int ba = -1;
+            bool bp = true;
+            auto run = [&]() {
+            if (!(d[axis] > 0.f)) return;  // flat box: nothing to cut on this axis
+                const float lo = nb.mn[axis], hi = nb.mx[axis];
+                for (size_t i = 0; i < n; ++i) {
+                    const Box& b = cb[i];  // already inside the node box
+                    edges[2 * i] = {b.mn[axis], (uint32_t)i << 1};
+                    edges[2 * i + 1] = {b.mx[axis], ((uint32_t)i << 1) | 1u};
                 }
-                n_above -= ends;
-                const bool at_lo = t == lo, at_hi = t == hi;
-                if ((!at_lo && !at_hi) || planar > 0) {
-                    float below_sa = 2.f * (d[a1] * d[a2] + (t - lo) * (d[a1] + d[a2]));
-                    float above_sa = 2.f * (d[a1] * d[a2] + (hi - t) * (d[a1] + d[a2]));
-                    float pb = below_sa * inv_total_sa, pa = above_sa * inv_total_sa;
-                    for (int side = 0; side < 2; ++side) {
-                        bool planar_below = side == 0;
-                        if (at_lo && !planar_below) continue;  // would reproduce the parent
-                        if (at_hi && planar_below) continue;
-                        if (planar == 0 && !planar_below) continue;
-                        size_t nbel = n_below + (planar_below ? planar : 0);
-                        size_t nabv = n_above + (planar_below ? 0 : planar);
-                        float eb = (nabv == 0 || nbel == 0) ? empty_bonus : 0.f;
-                        float cost = trav_cost + isect_cost * (1.f - eb) * (pb * (float)nbel + pa * (float)nabv);
-                        if (cost < best_cost) {
-                            best_cost = cost;
-                            best_axis = axis;
-                            best_split = t;
-                            best_planar_below = planar_below;
+                std::sort(edges.begin(), edges.end(), [](const Edge& a, const Edge& b) { return a.t < b.t; });
+                // Candidate planes = distinct (clamped) AABB bounds.  For a plane at t:
+                //   L = { min < t }, R = { max > t }, P = { min == max == t } (lying in the plane)
+                // A primitive that only touches the plane from one side stays on that side; P goes
+                // to whichever side is cheaper.  A plane ON the node boundary is allowed when it
+                // peels planar primitives into a zero-thickness child (a ground plane at the
+                // bottom of the scene box): rays that never reach the plane skip them entirely.
+                size_t n_below = 0, n_above = n;
+                int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+                for (size_t i = 0; i < 2 * n;) {
+                    float t = edges[i].t;
+                    size_t j = i, ends = 0, starts = 0, planar = 0;
+                    for (; j < 2 * n && edges[j].t == t; ++j) {
+                        if (edges[j].key & 1u) ++ends;
+                        else {
+                            ++starts;
+                            if (cb[edges[j].key >> 1].mx[axis] == t) ++planar;
                         }
                     }
+                    n_above -= ends;
+                    const bool at_lo = t == lo, at_hi = t == hi;
+                    if ((!at_lo && !at_hi) || planar > 0) {
+                        float below_sa = 2.f * (d[a1] * d[a2] + (t - lo) * (d[a1] + d[a2]));
+                        float above_sa = 2.f * (d[a1] * d[a2] + (hi - t) * (d[a1] + d[a2]));
+                        float pb = below_sa * inv_total_sa, pa = above_sa * inv_total_sa;
+                        for (int side = 0; side < 2; ++side) {
+                            bool planar_below = side == 0;
+                            if (at_lo && !planar_below) continue;  // would reproduce the parent
+                            if (at_hi && planar_below) continue;
+                            if (planar == 0 && !planar_below) continue;
+                            size_t nbel = n_below + (planar_below ? planar : 0);
+                            size_t nabv = n_above + (planar_below ? 0 : planar);
+                            float eb = (nabv == 0 || nbel == 0) ? empty_bonus : 0.f;
+                            float cost = trav_cost + isect_cost * (1.f - eb) * (pb * (float)nbel + pa * (float)nabv);
+                            if (cost < bc) {
+                                bc = cost;
+                                ba = axis;
+                                bs = t;
+                                bp = planar_below;
+                            }
+                        }
+                    }
+                    n_below += starts;
+                    i = j;
                 }
-                n_below += starts;
-                i = j;
-            }
+            };
+            run();
+            out.cost = bc;
+            out.split = bs;
+            out.axis = ba;
+            out.planar_below = bp;
+        };
+        AxisBest per_axis[3];
+        if ((int)level < par_levels && n > 100000) {   // the top of a large tree: the three sweeps side by side
+            std::vector<Edge> e0, e1, e2;
+            auto f1 = std::async(std::launch::async, [&] { sweep(1, per_axis[1], e1); });
+            auto f2 = std::async(std::launch::async, [&] { sweep(2, per_axis[2], e2); });
+            sweep(0, per_axis[0], e0);
+            f1.get();
+            f2.get();
+        } else {
+            std::vector<Edge> edges;
+            for (int axis = 0; axis < 3; ++axis) sweep(axis, per_axis[axis], edges);
         }
+        float best_split = 0.f;
+        bool best_planar_below = true;
+        for (int axis = 0; axis < 3; ++axis)
+            if (per_axis[axis].axis >= 0 && per_axis[axis].cost < best_cost) {
+                best_cost = per_axis[axis].cost;
+                best_axis = axis;
+                best_split = per_axis[axis].split;
+                best_planar_below = per_axis[axis].planar_below;
+            }
         if (best_cost > old_cost) ++bad;
         // small nodes stop as soon as splitting no longer pays (Wald's automatic
         // termination); large ones tolerate a few bad refines like pbrt does
@@ -240,33 +275,53 @@ struct Builder {
         ab.mn[best_axis] = split;
         std::vector<uint32_t> below, above;
         std::vector<Box> below_cb, above_cb;
-        below.reserve(n);
-        above.reserve(n);
-        below_cb.reserve(n);
-        above_cb.reserve(n);
-        for (size_t i = 0; i < n; ++i) {
-            uint32_t p = prims[i];
-            float mn = cb[i].mn[best_axis], mx = cb[i].mx[best_axis];
-            bool planar = mn == best_split && mx == best_split;
-            bool to_below = mn < best_split || (planar && best_planar_below);
-            bool to_above = mx > best_split || (planar && !best_planar_below);
-            for (int side = 0; side < 2; ++side) {
-                if (!(side == 0 ? to_below : to_above)) continue;
-                const Box& child = side == 0 ? bb : ab;
-                Box c;
-                if (geom[p].is_tri && clip) {
-                    if (!clip_triangle_bounds(geom[p], boxes[p], child, &pads[(size_t)p * 3], c)) continue;  // misses this child
-                } else {
-                    for (int a = 0; a < 3; ++a) {
-                        c.mn[a] = std::max(cb[i].mn[a], child.mn[a]);
-                        c.mx[a] = std::min(cb[i].mx[a], child.mx[a]);
+        // (range [i0, i1) of the node's primitives into the given lists: in order, so the lists stay sorted by id)
+        auto classify = [&](size_t i0, size_t i1, std::vector<uint32_t>& bl, std::vector<Box>& bl_cb, std::vector<uint32_t>& ab_,
+                            std::vector<Box>& ab_cb) {
+            for (size_t i = i0; i < i1; ++i) {
+                uint32_t p = prims[i];
+                float mn = cb[i].mn[best_axis], mx = cb[i].mx[best_axis];
+                bool planar = mn == best_split && mx == best_split;
+                bool to_below = mn < best_split || (planar && best_planar_below);
+                bool to_above = mx > best_split || (planar && !best_planar_below);
+                for (int side = 0; side < 2; ++side) {
+                    if (!(side == 0 ? to_below : to_above)) continue;
+                    const Box& child = side == 0 ? bb : ab;
+                    Box c;
+                    if (geom[p].is_tri && clip) {
+                        if (!clip_triangle_bounds(geom[p], boxes[p], child, &pads[(size_t)p * 3], c)) continue;  // misses this child
+                    } else {
+                        for (int a = 0; a < 3; ++a) {
+                            c.mn[a] = std::max(cb[i].mn[a], child.mn[a]);
+                            c.mx[a] = std::min(cb[i].mx[a], child.mx[a]);
+                        }
                     }
+                    (side == 0 ? bl : ab_).push_back(p);
+                    (side == 0 ? bl_cb : ab_cb).push_back(c);
                 }
-                (side == 0 ? below : above).push_back(p);
-                (side == 0 ? below_cb : above_cb).push_back(c);
             }
+        };
+        if ((int)level < par_levels && n > 100000) {   // the top of a large tree: sixteen ranges side by side, joined in order
+            constexpr size_t R = 16;
+            std::vector<uint32_t> pb[R], pa[R];
+            std::vector<Box> pbc[R], pac[R];
+            std::vector<std::future<void>> fs;
+            for (size_t r = 0; r < R; ++r)
+                fs.push_back(std::async(std::launch::async, [&, r] { classify(n * r / R, n * (r + 1) / R, pb[r], pbc[r], pa[r], pac[r]); }));
+            for (auto& f : fs) f.get();
+            for (size_t r = 0; r < R; ++r) {
+                below.insert(below.end(), pb[r].begin(), pb[r].end());
+                below_cb.insert(below_cb.end(), pbc[r].begin(), pbc[r].end());
+                above.insert(above.end(), pa[r].begin(), pa[r].end());
+                above_cb.insert(above_cb.end(), pac[r].begin(), pac[r].end());
+            }
+        } else {
+            below.reserve(n);
+            above.reserve(n);
+            below_cb.reserve(n);
+            above_cb.reserve(n);
+            classify(0, n, below, below_cb, above, above_cb);
         }
-        std::vector<Edge>().swap(edges);
         std::vector<uint32_t>().swap(prims);
         std::vector<Box>().swap(cb);
 
@@ -274,7 +329,7 @@ struct Builder {
         out.nodes.push_back({0, 0});
         out.sa_interior += area(nb);
         uint32_t above_idx;
-        if ((int)level < par_levels && n > 20000) {
+        if ((int)level < par_levels && n > 4000) {
             auto fut = std::async(std::launch::async, [&, this]() {
                 auto sub = std::make_unique<Sub>();
                 build(*sub, ab, std::move(above), std::move(above_cb), depth_left - 1, bad, level + 1);

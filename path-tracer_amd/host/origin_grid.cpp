@@ -434,7 +434,7 @@ struct Builder {
     // fn(index, thread) over [0, n) on every hardware thread, dynamic chunks
     template <class F>
     static void parallel(size_t n, F&& fn, size_t chunk = 1) {
-        unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        unsigned nt = std::max(1u, std::min(96u, std::thread::hardware_concurrency()));
         if (const char* e = getenv("PT_HOST_THREADS")) nt = std::max(1, atoi(e));
         if (n <= chunk || nt == 1) {
             for (size_t i = 0; i < n; ++i) fn(i, 0);
