@@ -225,9 +225,16 @@ PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursors, uint32_t n, bool need
 #define WF_PRIMARY_WAVES 5   // the bounce-0 trace and the opaque trace are held to 96 registers (they fit without spilling)
 #endif
 
+#ifndef WF_LEAN_TRAV
+#define WF_LEAN_TRAV 0   // 1: the walk keeps neither 1/d nor the key scale in registers (re-derived where used): -4 registers
+#endif
 struct Trav {
-    f3 o, d, inv;
-    float tmin, tmax, key_scale;
+    f3 o, d;
+#if !WF_LEAN_TRAV
+    f3 inv;
+    float key_scale;
+#endif
+    float tmin, tmax;
     uint32_t node;
     uint32_t dneg;   // bit a: d[a] <= 0 (the tie rule of the child order)
     int sp;
@@ -307,12 +314,15 @@ PT_D bool trav_start(const DevScene& S, Trav& T, f3 o, f3 d, float t_start) {
     T.d = d;
     // v_rcp_f32 (1 ulp) instead of three IEEE divisions (~10 instructions each): the reciprocals only
     // place the split planes along the ray, and every plane test carries a 1e-5 relative slack
-    T.inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const f3 inv3 = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+#if !WF_LEAN_TRAV
+    T.inv = inv3;
     float dlen = mag3(d);
     T.key_scale = dlen < 1.0f ? dlen : 1.0f;
+#endif
     T.dneg = (d.x <= 0.f ? 1u : 0u) | (d.y <= 0.f ? 2u : 0u) | (d.z <= 0.f ? 4u : 0u);
     float tmin = t_start, tmax = INFINITY;
-    const float oa[3] = {o.x, o.y, o.z}, ia[3] = {T.inv.x, T.inv.y, T.inv.z};
+    const float oa[3] = {o.x, o.y, o.z}, ia[3] = {inv3.x, inv3.y, inv3.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float tn = (S.bounds_min[a] - oa[a]) * ia[a];
@@ -334,12 +344,27 @@ PT_D bool trav_start(const DevScene& S, Trav& T, f3 o, f3 d, float t_start) {
 
 // Move to the next stacked segment; false when the walk is over (stack empty or the segment
 // starts beyond `limit`, the best hit key so far).
+PT_D float trav_key_scale(const Trav& T) {   // key >= t * min(1, |d|) (next_hit)
+#if WF_LEAN_TRAV
+    const float dlen = mag3(T.d);
+    return dlen < 1.0f ? dlen : 1.0f;
+#else
+    return T.key_scale;
+#endif
+}
+PT_D float trav_inv_axis(const Trav& T, unsigned long long ax0, unsigned long long ax1) {   // 1 / d[axis] (v_rcp_f32, as trav_start)
+#if WF_LEAN_TRAV
+    return __builtin_amdgcn_rcpf(wf_select(ax0, T.d.x, wf_select(ax1, T.d.y, T.d.z)));
+#else
+    return wf_select(ax0, T.inv.x, wf_select(ax1, T.inv.y, T.inv.z));
+#endif
+}
 PT_D bool trav_pop(Trav& T, const TravStack& st, float limit) {
     if (T.sp == 0) return false;
     --T.sp;
     T.tmin = T.tmax;
     stack_get(st, T.sp, T.node, T.tmax);
-    return !(T.tmin * T.key_scale > limit * PT_EXIT_REL + PT_EXIT_ABS);
+    return !(T.tmin * trav_key_scale(T) > limit * PT_EXIT_REL + PT_EXIT_ABS);
 }
 
 // Start a cast whose origin lies on a primitive (every ray after the camera ray: origin = hit point + normal * 1e-5,
@@ -377,7 +402,7 @@ PT_D bool trav_enter(const DevScene& S, Trav& T, const TravStack& st, f3 o, f3 d
                 const uint32_t axis = w1 & 3u;
                 const unsigned long long ax0 = __builtin_amdgcn_uicmp(axis, 0u, 32), ax1 = __builtin_amdgcn_uicmp(axis, 1u, 32);
                 const float o_a = wf_select(ax0, o.x, wf_select(ax1, o.y, o.z));
-                const float i_a = wf_select(ax0, T.inv.x, wf_select(ax1, T.inv.y, T.inv.z));
+                const float i_a = trav_inv_axis(T, ax0, ax1);
                 const float tplane = (split - o_a) * i_a;
                 // the origin must be on the near side of the plane (or in it)
                 bad |= (w1 & 4u) ? (o_a > split ? 1u : 0u) : (o_a < split ? 1u : 0u);
@@ -436,7 +461,7 @@ PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float l
         const float split = __uint_as_float(nd.x);
         const unsigned long long ax0 = __builtin_amdgcn_uicmp(axis, 0u, 32), ax1 = __builtin_amdgcn_uicmp(axis, 1u, 32);  // EQ
         const float o_a = wf_select(ax0, T.o.x, wf_select(ax1, T.o.y, T.o.z));
-        const float i_a = wf_select(ax0, T.inv.x, wf_select(ax1, T.inv.y, T.inv.z));
+        const float i_a = trav_inv_axis(T, ax0, ax1);
         const float tplane = (split - o_a) * i_a;
         // below child first iff o < split, or o == split and d <= 0
         const uint32_t dn = (T.dneg >> axis) & 1u;
@@ -482,7 +507,10 @@ PT_D uint32_t wf_scan_inclusive(uint32_t v) {
 // (The 48-byte leaf records are read with plain loads: a primitive is referenced from ~7 leaves, and
 // marking these loads non-temporal cost 19 % of the trace stage.)
 // Closest-hit candidate update for one leaf (same acceptance rule as next_hit()).
-template <bool COUNT>
+#ifndef WF_LEAN_HIT
+#define WF_LEAN_HIT 0   // 1: the opaque cast keeps only (key, order, id) of its best hit across the walk; u, v and the flags are
+#endif                  //    re-derived once, at the end, by testing the winning primitive again (same arithmetic, same bits)
+template <bool COUNT, bool LEAN = false>
 PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_prev, uint32_t ord_prev, RawHit& best,
                        LocalCtr& lc, uint32_t& mailbox) {
     const float4* lp = S.leaf_prims + (size_t)leaf.x * 3;
@@ -509,9 +537,11 @@ PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_pre
                 best.key = dist;
                 best.ord = ord;
                 best.pid = pid;
-                best.u = u;
-                best.v = v;
-                best.flags = bf ? 1u : 0u;
+                if (!LEAN) {
+                    best.u = u;
+                    best.v = v;
+                    best.flags = bf ? 1u : 0u;
+                }
             }
         } else {
             float t[2], key[2];
@@ -523,12 +553,37 @@ PT_D void leaf_closest(const DevScene& S, const Trav& T, uint2 leaf, float t_pre
                     best.key = key[k];
                     best.ord = ord;
                     best.pid = pid;
-                    best.u = t[k];
-                    best.v = 0.f;
-                    best.flags = 2u | (ex[k] ? 4u : 0u);
+                    if (!LEAN) {
+                        best.u = t[k];
+                        best.v = 0.f;
+                        best.flags = 2u | (ex[k] ? 4u : 0u);
+                    }
                 }
             }
         }
+    }
+}
+// LEAN: u, v and the flags of the winning hit (key, ord, pid), by testing that primitive once more
+PT_D void rederive_hit(const DevScene& S, const Trav& T, RawHit& best) {
+    const float4* pp = S.prim_pos + (size_t)PT_PRIM_INDEX(best.pid) * 3;
+    float4 q0, q1, q2;
+    load_prim_record(pp, q0, q1, q2);
+    if (!(best.pid & PT_PRIM_SPHERE)) {
+        float dist, u, v;
+        bool bf;
+        (void)isect_triangle(T.o, T.d, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), dist, u, v, bf);
+        best.u = u;
+        best.v = v;
+        best.flags = bf ? 1u : 0u;
+    } else {
+        float t[2], key[2];
+        bool ex[2];
+        (void)isect_sphere(T.o, T.d, mk3(q0.x, q0.y, q0.z), q1.x, t, key, ex);
+        const uint32_t k = best.ord & 1u;   // (entry hit first: order bit 0 = the exit hit)
+        const bool second = k != 0u && !ex[0];
+        best.u = second ? t[1] : t[0];
+        best.v = 0.f;
+        best.flags = 2u | (k ? 4u : 0u);
     }
 }
 
@@ -725,6 +780,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                 best = kept;
                 hit = true;
             }
+            if (WF_LEAN_HIT && !ALPHA && hit) rederive_hit(S, T, best);
             wf_store_hit(hits, W.cap, idx, best, hit);
             if (ALPHA) draws[idx] = draw;   // rng.gen() calls of the path so far (the alpha walk may have drawn)
             active = false;
@@ -865,7 +921,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
         }
 #else
         if (lstate == WF_LANE_LEAF) {
-            leaf_closest<COUNT>(S, T, T.leaf, t_prev, ord_prev, best, lc, mailbox);
+            leaf_closest<COUNT, WF_LEAN_HIT && !ALPHA>(S, T, T.leaf, t_prev, ord_prev, best, lc, mailbox);
             lstate = trav_pop(T, st, best.key) ? WF_LANE_WALK : WF_LANE_DONE;
         }
 #endif
@@ -1026,7 +1082,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
                     T.tmin = pool_tmin[group][slot];
                     T.tmax = pool_tmax[group][slot];
                     T.sp = 0;
-                    busy = !(T.tmin * T.key_scale > gkey * PT_EXIT_REL + PT_EXIT_ABS);
+                    busy = !(T.tmin * trav_key_scale(T) > gkey * PT_EXIT_REL + PT_EXIT_ABS);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
