@@ -96,3 +96,26 @@ def test_cli_several_devices_equal_one(tmp_path, pta, gpu_scene_cache):
     assert np.array_equal(np.asarray(Image.open(out)).reshape(-1, 3), rgb)
     r = run("render", str(SCENES / "cube" / "scene.isf"), "-q", "-o", str(out), "--devices", "0,,1")
     assert r.returncode == 2 and "invalid value" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_two_distinct_devices_gather_over_rccl(tmp_path, pta, gpu_scene_cache):
+    """--devices 0,1 on a host with at least two GPUs: the library's own exchange step (pt_comm_create_all,
+    ncclAllGather of the packed slices + scatter, one host thread per device) between REAL ranks.  Skipped on a
+    one-GPU box; on the 8-GPU node this is the multi-rank RCCL path's first run on hardware."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs two GPUs")
+    prof = tmp_path / "p.yml"
+    prof.write_text("resolution:\n  width: 320\n  height: 200\nsamples: 8\nbounces: 3\n")
+    rgb, _ = gpu_scene_cache("alpha_transparency").render(pta.Profile.make(320, 200, 8, 3))
+    for devs in ("0,1", ",".join(str(k) for k in range(min(n, 8)))):
+        out = tmp_path / f"multi_{devs.count(',') + 1}.png"
+        r = run("render", str(SCENES / "alpha_transparency" / "scene.isf"), "-q", "-p", str(prof), "-o", str(out),
+                "--devices", devs, "--stats")
+        assert r.returncode == 0, r.stderr
+        assert '"gather": "rccl"' in r.stderr
+        assert np.array_equal(np.asarray(Image.open(out)).reshape(-1, 3), rgb), devs
