@@ -30,15 +30,38 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
 
+#include <sys/mman.h>
+
 #include "host_common.hpp"
 
 namespace pth {
 namespace {
+
+// The grids' two big arrays (400 MB - 1.6 GB of cell offsets, as much again in list entries): anonymous mappings with
+// transparent huge pages asked for.  Faulted in 4 KB at a time by ~100 threads at once they cost 0.5 s of page-fault
+// contention per grid (and slowed the KD build running beside them); 2 MB pages are 512x fewer faults.  Zero-filled.
+size_t big_size(size_t bytes) { return (std::max<size_t>(bytes, 1) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); }
+void* big_alloc(size_t bytes) {
+    const size_t n = big_size(bytes) + ((size_t)2 << 20);   // room to align the start to 2 MB
+    void* raw = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (raw == MAP_FAILED) throw std::bad_alloc();
+    uintptr_t a = ((uintptr_t)raw + (((uintptr_t)2 << 20) - 1)) & ~(((uintptr_t)2 << 20) - 1);
+    // (trim the unaligned head and the unused tail so that munmap(ptr, big_size) releases exactly the block)
+    if (a > (uintptr_t)raw) munmap(raw, a - (uintptr_t)raw);
+    const uintptr_t end = a + big_size(bytes), raw_end = (uintptr_t)raw + n;
+    if (raw_end > end) munmap((void*)end, raw_end - end);
+    madvise((void*)a, big_size(bytes), MADV_HUGEPAGE);
+    return (void*)a;
+}
+void big_free(void* p, size_t bytes) {
+    if (p) munmap(p, big_size(bytes));
+}
 
 constexpr double kEps32 = 5.9604644775390625e-8;  // 2^-24
 constexpr int kMaxPoly = 24;                      // octagon clipped by four planes: <= 12 vertices
@@ -406,20 +429,26 @@ struct Builder {
         fps.resize(n_prims);
         prim_word.resize(n_prims);
         uint64_t prim = 0;
-        struct Span {
+        struct Span {   // a model, or 4096 triangles of a mesh (a scene is often ONE big mesh: a span per model was one thread)
             uint64_t prim0;
-            uint32_t model;
+            uint32_t model, tri0, tri1;
         };
         std::vector<Span> spans;
         for (uint32_t m = 0; m < d.n_models; ++m) {
-            spans.push_back({prim, m});
-            prim += d.models[m].kind == PT_MODEL_MESH ? d.models[m].tri_count : 1;
+            if (d.models[m].kind == PT_MODEL_MESH) {
+                for (uint32_t t0 = 0; t0 < d.models[m].tri_count; t0 += 4096u)
+                    spans.push_back({prim + t0, m, t0, std::min(d.models[m].tri_count, t0 + 4096u)});
+                prim += d.models[m].tri_count;
+            } else {
+                spans.push_back({prim, m, 0u, 0u});
+                prim += 1;
+            }
         }
         parallel(spans.size(), [&](size_t si, size_t) {
             const pt_model& mo = d.models[spans[si].model];
             uint64_t p = spans[si].prim0;
             if (mo.kind == PT_MODEL_MESH) {
-                for (uint32_t t = 0; t < mo.tri_count; ++t, ++p) {
+                for (uint32_t t = spans[si].tri0; t < spans[si].tri1; ++t, ++p) {
                     const float* tri = d.triangles + (size_t)(mo.tri_first + t) * 24;
                     fps[p] = P.ortho ? triangle_footprint_ortho(P, tri) : triangle_footprint(P, tri);
                     prim_word[p] = (uint32_t)p;
@@ -472,8 +501,17 @@ uint32_t auto_resolution(uint64_t n_prims) {
 // grids along a direction.
 void fill_lists(const pt_scene_desc& d, const GridParams& P, pth_origin_grid& g, std::chrono::steady_clock::time_point t0) {
     const uint64_t n_prims = pth_prim_count(&d);
+    const bool dbg = getenv("PT_DEBUG_SETUP") != nullptr;
+    auto t_ph = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (!dbg) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[grid %u] %-12s %.3f s\n", P.res, name, std::chrono::duration<double>(now - t_ph).count());
+        t_ph = now;
+    };
     Builder B(d, P);
     B.footprints();
+    phase("footprints");
     std::vector<uint32_t> global;
     for (uint64_t p = 0; p < n_prims; ++p)
         if (B.fps[p].global) global.push_back((uint32_t)p);
@@ -485,10 +523,19 @@ void fill_lists(const pt_scene_desc& d, const GridParams& P, pth_origin_grid& g,
         return;   // enabled = 0: too many primitives every ray would have to test
     }
 
-    // ---- pass 1: count the references of every cell
-    std::unique_ptr<uint32_t, void (*)(void*)> counts((uint32_t*)calloc(g.n_cells + 1, 4), free);
-    if (!counts) throw std::bad_alloc();
-    uint32_t* cnt = counts.get();
+    // ---- pass 1: count the references of every cell.  Layout trick: the array has n_cells + 2 words and the per-cell
+    // word lives at index cell + 1: after the scan it holds the cell's START, the fill pass advances it, and what is left
+    // is the cell's END = the next cell's start - i.e. read from index 0 the array IS the offset table (word 0 = the
+    // number of global entries in front), with no second cursor array and no copy.
+    const size_t off_bytes = (g.n_cells + 2) * 4;
+    struct BigPtr {
+        void* p;
+        size_t bytes;
+        ~BigPtr() { big_free(p, bytes); }
+        void* release() { void* q = p; p = nullptr; return q; }
+    };
+    BigPtr counts{big_alloc(off_bytes), off_bytes};
+    uint32_t* cnt = (uint32_t*)counts.p + 1;
     const size_t chunk = 256;
     Builder::parallel((n_prims + chunk - 1) / chunk, [&](size_t ci, size_t) {
         for (uint64_t p = ci * chunk; p < std::min<uint64_t>(n_prims, (ci + 1) * chunk); ++p) {
@@ -497,25 +544,37 @@ void fill_lists(const pt_scene_desc& d, const GridParams& P, pth_origin_grid& g,
             rasterize(P, fp, [&](size_t cell) { __atomic_fetch_add(&cnt[cell], 1u, __ATOMIC_RELAXED); });
         }
     });
-    // ---- exclusive scan (the global list sits in front)
-    uint64_t total = global.size();
-    for (uint64_t c = 0; c < g.n_cells; ++c) {
-        uint32_t n = cnt[c];
-        if (total > 0xffffffffull) fail(PT_ERR_UNSUPPORTED, "origin grid: more than 2^32 references (lower PT_OG_RES)");
-        cnt[c] = (uint32_t)total;
-        total += n;
-    }
+    phase("count");
+    // ---- exclusive scan (the global list sits in front), in parallel: sums of 1 Mi-cell chunks, their prefix, then every
+    // chunk scans itself and writes the fill cursors beside the offsets (one thread over 100 M cells, two fresh 400 MB
+    // arrays faulted in by it, was 0.7 of the grid's 1.1 s)
+    const uint64_t scan_chunk = 1ull << 20, n_chunks = (g.n_cells + scan_chunk - 1) / scan_chunk;
+    std::vector<uint64_t> chunk_sum(n_chunks + 1, 0);
+    Builder::parallel(n_chunks, [&](size_t ci, size_t) {
+        uint64_t sum = 0;
+        for (uint64_t c = ci * scan_chunk; c < std::min<uint64_t>(g.n_cells, (ci + 1) * scan_chunk); ++c) sum += cnt[c];
+        chunk_sum[ci + 1] = sum;
+    });
+    chunk_sum[0] = global.size();
+    for (uint64_t ci = 0; ci < n_chunks; ++ci) chunk_sum[ci + 1] += chunk_sum[ci];
+    const uint64_t total = chunk_sum[n_chunks];
     if (total > 0xffffffffull) fail(PT_ERR_UNSUPPORTED, "origin grid: more than 2^32 references (lower PT_OG_RES)");
-    cnt[g.n_cells] = (uint32_t)total;
+    Builder::parallel(n_chunks, [&](size_t ci, size_t) {
+        uint64_t run = chunk_sum[ci];
+        for (uint64_t c = ci * scan_chunk; c < std::min<uint64_t>(g.n_cells, (ci + 1) * scan_chunk); ++c) {
+            const uint32_t n = cnt[c];
+            cnt[c] = (uint32_t)run;
+            run += n;
+        }
+    });
     g.n_refs = total;
-    std::unique_ptr<pth_grid_ref, void (*)(void*)> refs((pth_grid_ref*)malloc(std::max<uint64_t>(1, total) * sizeof(pth_grid_ref)), free);
-    std::unique_ptr<uint32_t, void (*)(void*)> cursor((uint32_t*)malloc((g.n_cells + 1) * 4), free);
-    if (!refs || !cursor) throw std::bad_alloc();
-    memcpy(cursor.get(), cnt, (g.n_cells + 1) * 4);
-    for (size_t i = 0; i < global.size(); ++i) refs.get()[i] = pth_grid_ref{B.prim_word[global[i]], 0.f};
-    // ---- pass 2: fill
-    uint32_t* cur = cursor.get();
-    pth_grid_ref* rf = refs.get();
+    const size_t ref_bytes = std::max<uint64_t>(1, total) * sizeof(pth_grid_ref);
+    BigPtr refs{big_alloc(ref_bytes), ref_bytes};
+    phase("scan + alloc");
+    pth_grid_ref* rf = (pth_grid_ref*)refs.p;
+    for (size_t i = 0; i < global.size(); ++i) rf[i] = pth_grid_ref{B.prim_word[global[i]], 0.f};
+    // ---- pass 2: fill (advances the cells' start words to their ends)
+    uint32_t* cur = cnt;
     Builder::parallel((n_prims + chunk - 1) / chunk, [&](size_t ci, size_t) {
         for (uint64_t p = ci * chunk; p < std::min<uint64_t>(n_prims, (ci + 1) * chunk); ++p) {
             const Footprint& fp = B.fps[p];
@@ -524,13 +583,16 @@ void fill_lists(const pt_scene_desc& d, const GridParams& P, pth_origin_grid& g,
             rasterize(P, fp, [&](size_t cell) { rf[__atomic_fetch_add(&cur[cell], 1u, __ATOMIC_RELAXED)] = r; });
         }
     });
+    phase("fill");
+    const uint32_t* off = (const uint32_t*)counts.p;   // off[c] = start of cell c, off[c + 1] = its end
+    ((uint32_t*)counts.p)[0] = (uint32_t)global.size();
     // ---- every list in ascending (distance, primitive) order: deterministic, and what the early exits need
     const size_t cell_chunk = 4096;
     std::atomic<uint32_t> longest{0};
     Builder::parallel((g.n_cells + cell_chunk - 1) / cell_chunk, [&](size_t ci, size_t) {
         uint32_t local_max = 0;
         for (uint64_t c = ci * cell_chunk; c < std::min<uint64_t>(g.n_cells, (ci + 1) * cell_chunk); ++c) {
-            uint32_t b = cnt[c], e = cnt[c + 1];
+            uint32_t b = off[c], e = off[c + 1];
             local_max = std::max(local_max, e - b);
             if (e - b > 1)
                 std::sort(rf + b, rf + e, [](const pth_grid_ref& x, const pth_grid_ref& y) {
@@ -541,9 +603,10 @@ void fill_lists(const pt_scene_desc& d, const GridParams& P, pth_origin_grid& g,
         while (local_max > seen && !longest.compare_exchange_weak(seen, local_max)) {
         }
     });
+    phase("sort");
     g.max_cell_refs = longest.load();
-    g.cell_off = counts.release();
-    g.refs = refs.release();
+    g.cell_off = (uint32_t*)counts.release();
+    g.refs = (pth_grid_ref*)refs.release();
     g.enabled = 1;
     g.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -691,8 +754,8 @@ int pth_ortho_grid_build(const pt_scene_desc* desc, const float direction[3], ui
 
 void pth_origin_grid_free(pth_origin_grid* g) {
     if (!g) return;
-    free(g->cell_off);
-    free(g->refs);
+    pth::big_free(g->cell_off, (g->n_cells + 2) * 4);
+    pth::big_free(g->refs, std::max<uint64_t>(1, g->n_refs) * sizeof(pth_grid_ref));
     g->cell_off = nullptr;
     g->refs = nullptr;
     g->enabled = 0;
