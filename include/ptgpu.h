@@ -357,6 +357,16 @@ int pt_trace_rays(const pt_scene* scene, const float* rays, uint64_t n, pt_hit* 
 int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint32_t* start_prims, uint64_t n,
                             uint32_t mode, pt_hit* out);
 
+/* The origin grids of a scene as the DEVICE built them (csrc/pt_grid_build.h): which = 0 the camera grid, 1 + i the grid
+ * of light i.  pt_scene_grid_header fills the header fields of a pth_origin_grid (include/pthost.h; enabled = 0: the
+ * scene has no such grid; cell_off / refs are left null), pt_scene_grid_copy copies the n_cells + 1 cell offsets and
+ * the n_refs list entries into caller-provided host arrays - for the tests, which compare them with the host builder's
+ * (pth_origin_grid_build: the same lists byte for byte) and run the conservativeness checks on them. */
+struct pth_origin_grid;
+struct pth_grid_ref;
+int pt_scene_grid_header(const pt_scene* scene, uint32_t which, struct pth_origin_grid* out);
+int pt_scene_grid_copy(const pt_scene* scene, uint32_t which, uint32_t* cell_off, struct pth_grid_ref* refs);
+
 /* Up to max_hits hits per ray in the reference's sorted order (all hits,
  * stable by (dist, primitive order)); counts[i] = number written. */
 int pt_trace_rays_all(const pt_scene* scene, const float* rays, uint64_t n, uint32_t max_hits,

@@ -175,7 +175,8 @@ HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_s
 GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_prep_create", "pt_prep_destroy", "pt_scene_create_from_prep",
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_gather_tiles", "pt_render_gathered", "pt_local_pixel_count", "pt_local_pixel_map",
                "pt_render", "pt_render_device", "pt_debug_render", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
-               "pt_scene_get_info", "pt_trace_rays", "pt_trace_rays_wavefront", "pt_trace_rays_all", "pt_intersect_triangles",
+               "pt_scene_get_info", "pt_scene_grid_header", "pt_scene_grid_copy", "pt_trace_rays", "pt_trace_rays_wavefront",
+               "pt_trace_rays_all", "pt_intersect_triangles",
                "pt_rng_words", "pt_eval_math", "pt_measure_copy_bandwidth", "pt_measure_gather_rate", "pt_last_error",
                "pt_version"]
 
@@ -257,6 +258,8 @@ def gpu_lib():
         L.pt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
         L.pt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp]
         L.pt_trace_rays_wavefront.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, vp]
+        L.pt_scene_grid_header.argtypes = [vp, C.c_uint32, vp]
+        L.pt_scene_grid_copy.argtypes = [vp, C.c_uint32, vp, vp]
         L.pt_trace_rays_all.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
         L.pt_intersect_triangles.argtypes = [C.c_int, vp, vp, C.c_uint64, vp]
         L.pt_rng_words.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]
@@ -347,6 +350,24 @@ class OriginGrid:
             self.ref_prim = raw[0::2]
             self.ref_mindist = raw[1::2].view(np.float32)
 
+    @classmethod
+    def from_device(cls, gpu_scene, which):
+        """The grid the DEVICE built for a scene (csrc/pt_grid_build.h): which = 0 camera, 1 + i light i."""
+        import numpy as np
+        self = cls.__new__(cls)
+        self.c = OriginGridC()
+        self._owned = False
+        check_gpu(gpu_scene.lib.pt_scene_grid_header(gpu_scene.handle, which, C.byref(self.c)))
+        self.enabled = bool(self.c.enabled)
+        self.res, self.n_global, self.n_refs = int(self.c.res), int(self.c.n_global), int(self.c.n_refs)
+        if self.enabled:
+            self.cell_off = np.zeros(int(self.c.n_cells) + 1, np.uint32)
+            raw = np.zeros(max(1, self.n_refs) * 2, np.uint32)
+            check_gpu(gpu_scene.lib.pt_scene_grid_copy(gpu_scene.handle, which, self.cell_off.ctypes.data, raw.ctypes.data))
+            self.ref_prim = raw[0::2]
+            self.ref_mindist = raw[1::2].view(np.float32)
+        return self
+
     def cells(self, w):
         """Cell index of every direction w [n, 3] - orthographic grids: of every ray ORIGIN w - in the f32 arithmetic
         of the device (csrc/pt_grid.h og_cell / og_cell_ortho)."""
@@ -394,7 +415,8 @@ class OriginGrid:
         return self.ref_prim[sel], self.ref_mindist[sel]
 
     def close(self):
-        host_lib().pth_origin_grid_free(C.byref(self.c))
+        if getattr(self, "_owned", True):
+            host_lib().pth_origin_grid_free(C.byref(self.c))
 
     def __del__(self):
         try:

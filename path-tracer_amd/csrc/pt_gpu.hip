@@ -38,6 +38,7 @@
 #include "pt_integrator.h"
 #include "pt_wavefront.h"
 #include "pt_grid_kernels.h"
+#include "pt_grid_build.h"
 #include "pthost.h"
 
 // ------------------------------------------------------------------ errors
@@ -470,6 +471,8 @@ struct pt_scene {
     pt_scene_info info{};
     bool ortho_light_grids = false;   // some light grid is orthographic (a directional light): kernel variants DIRL
     std::vector<uint32_t> host_prim_entry;
+    std::vector<pth_origin_grid> grid_headers;   // device-built grids: [0] camera, [1 + i] light i (enabled = 0: none)
+    std::vector<DevGrid> host_light_grids;
     mutable pt_timing timing{};
     mutable pt_counters counters{};
     mutable DeviceBuffer accum_scratch, counter_buf, staging_buf;
@@ -548,6 +551,20 @@ struct pt_prep {
     std::unique_ptr<Grid> cam_grid;
     std::vector<std::unique_ptr<Grid>> light_grids;
     bool all_lights_gridded = false;
+    // grids built on the device at upload time (csrc/pt_grid_build.h; PT_OG_HOST=1: built here, on the host, as above):
+    // what every grid needs beside the primitives - its parameters and header - and the primitives' geometry as the
+    // footprints take it (9 floats: three positions, or centre + radius), with the id | sphere-bit word
+    struct GridJob {
+        pth::og::GridParams params;
+        pth_origin_grid hdr{};
+        bool valid = false;
+    };
+    bool device_grids = false;
+    GridJob cam_job;
+    std::vector<GridJob> light_jobs;
+    std::vector<float> og_geom;
+    std::vector<uint32_t> og_words;
+    double og_budget = 0;
 };
 
 namespace {
@@ -623,6 +640,35 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
             while (res > 512u && estimate(res) > budget) res >>= 1;
         }
         double grid_bytes = 0;
+        static const bool host_grids = [] {
+            const char* e = getenv("PT_OG_HOST");
+            return e && *e && atoi(e) != 0;
+        }();
+        if (!host_grids) {   // the device builds them at upload time: only the parameters are derived here
+            P.device_grids = true;
+            P.og_budget = budget;
+            const float max_normal = 1.5f;
+            if (grids_on && n_prims > 0 && fro > 0 && fro < 64.0 && estimate(res) <= budget)
+                P.cam_job.valid = pth::og_params_point(d, M + 12, res, 0.f, (float)(fro * 1.001), P.cam_job.params, P.cam_job.hdr);
+            bool all = grids_on && n_prims > 0 && lights_fit;
+            for (uint32_t i = 0; i < d.n_lights && all; ++i) {
+                pt_prep::GridJob job;
+                if (d.lights[i].kind == PT_LIGHT_POINT) {
+                    job.valid = pth::og_params_point(d, d.lights[i].vec, light_res, 1.05e-5f * max_normal, 1.001f, job.params, job.hdr);
+                } else {
+                    const float sd[3] = {-1.f * d.lights[i].vec[0], -1.f * d.lights[i].vec[1], -1.f * d.lights[i].vec[2]};
+                    job.valid = pth::og_params_ortho(d, sd, light_res, job.params, job.hdr);
+                }
+                if (!job.valid) all = false;
+                P.light_jobs.push_back(job);
+            }
+            if (!all) P.light_jobs.clear();
+            P.all_lights_gridded = all;
+            D.all_lights_gridded = all ? 1u : 0u;
+            D.light_grid_max_normal2 = max_normal * max_normal;
+            P.info.grid_build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_grid).count();
+            return;
+        }
         // (the camera grid on a thread of its own beside the light grids: every grid is its own count / scan / fill / sort)
         std::future<void> cam_done;
         if (grids_on && n_prims > 0 && fro > 0 && fro < 64.0 && estimate(res) <= budget) {
@@ -691,6 +737,8 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
     std::vector<float4>&attr = P.attr, &pos = P.pos;
     attr.resize(n_prims * 4);
     pos.resize(n_prims * 3);
+    P.og_geom.resize(n_prims * 9);
+    P.og_words.resize(n_prims);
     P.model_mat.resize(d.n_models);
     bool translucent = false;
     uint64_t prim = 0;
@@ -716,6 +764,11 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
                 pos[prim * 3 + 0] = make_float4(a[0], a[1], a[2], pbits);
                 pos[prim * 3 + 1] = make_float4(e1[0], e1[1], e1[2], e2[0]);
                 pos[prim * 3 + 2] = make_float4(e2[1], e2[2], 0.f, 0.f);
+                float* og = &P.og_geom[prim * 9];
+                og[0] = a[0]; og[1] = a[1]; og[2] = a[2];
+                og[3] = b[0]; og[4] = b[1]; og[5] = b[2];
+                og[6] = c[0]; og[7] = c[1]; og[8] = c[2];
+                P.og_words[prim] = pid;
             }
         } else {
             attr[prim * 4 + 0] = make_float4(mo.center[0], mo.center[1], mo.center[2], mo.radius);
@@ -727,6 +780,10 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
             pos[prim * 3 + 0] = make_float4(mo.center[0], mo.center[1], mo.center[2], pbits);
             pos[prim * 3 + 1] = make_float4(mo.radius, 0, 0, 0);
             pos[prim * 3 + 2] = make_float4(0, 0, 0, 0);
+            float* og = &P.og_geom[prim * 9];
+            og[0] = mo.center[0]; og[1] = mo.center[1]; og[2] = mo.center[2]; og[3] = mo.radius;
+            og[4] = og[5] = og[6] = og[7] = og[8] = 0.f;
+            P.og_words[prim] = pid;
             ++prim;
         }
     }
@@ -972,6 +1029,129 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
     P.info.kd_build_seconds = (float)kd.build_seconds;
 }
 
+// One origin grid built on the device (csrc/pt_grid_build.h) from the parameters / header prep_create derived.  Returns
+// false when the grid is not to be had - too many primitives every ray would have to test, more than 2^32 list entries,
+// the byte budget of the scene's grids exceeded, or the device out of memory: the casts it would have served take the
+// KD-tree.  On success the two arrays belong to the scene (s.allocations).
+bool device_grid_build(pt_scene& s, const pt_prep::GridJob& job, const float* d_geom, const uint32_t* d_words, uint32_t n_prims,
+                       const std::vector<uint32_t>& words, double& bytes_used, double budget, DevGrid& out, pth_origin_grid& hdr_out) {
+    memset(&out, 0, sizeof out);
+    if (!job.valid || n_prims == 0) return false;
+    static const uint32_t max_global = [] {
+        const char* e = getenv("PT_OG_MAX_GLOBAL");
+        return (uint32_t)(e && *e ? std::max(0, atoi(e)) : 64);
+    }();
+    const pth::og::GridParams& G = job.params;
+    pth_origin_grid hdr = job.hdr;
+    const uint64_t n_cells = hdr.n_cells;
+    const bool dbg = getenv("PT_DEBUG_SETUP") != nullptr;
+    auto t_ph = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (!dbg) return;
+        (void)hipDeviceSynchronize();
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[device grid %u] %-10s %.4f s\n", hdr.res, name, std::chrono::duration<double>(now - t_ph).count());
+        t_ph = now;
+    };
+    uint32_t *cnt_base = nullptr, *d_glob = nullptr, *d_bsum = nullptr;
+    uint2* d_refs = nullptr;
+    auto cleanup = [&]() {
+        for (void* q : {(void*)cnt_base, (void*)d_glob, (void*)d_bsum, (void*)d_refs})
+            if (q) (void)hipFree(q);
+        (void)hipGetLastError();
+    };
+    try {
+        const size_t off_bytes = (n_cells + 2) * 4;
+        if (bytes_used + (double)off_bytes > budget) return false;
+        HIP_CHECK(hipMalloc((void**)&cnt_base, off_bytes));
+        HIP_CHECK(hipMemsetAsync(cnt_base, 0, off_bytes, 0));
+        const uint32_t glob_cap = max_global + 1u;
+        HIP_CHECK(hipMalloc((void**)&d_glob, (glob_cap + 2u) * 4));   // [0] counter, [1] longest list, [2 ...] the list
+        HIP_CHECK(hipMemsetAsync(d_glob, 0, (glob_cap + 2u) * 4, 0));
+        phase("alloc");
+        const dim3 pg((n_prims + 3u) / 4u);   // a wavefront per primitive
+        hipLaunchKernelGGL((ogb::k_og_raster<0>), pg, dim3(256), 0, 0, G, d_geom, d_words, n_prims, cnt_base + 1, (uint2*)nullptr,
+                           d_glob + 2, d_glob, glob_cap);
+        HIP_CHECK(hipGetLastError());
+        phase("count");
+        const uint32_t n_blocks = (uint32_t)((n_cells + OG_SCAN_BLOCK - 1) / OG_SCAN_BLOCK);
+        HIP_CHECK(hipMalloc((void**)&d_bsum, (size_t)n_blocks * 4));
+        hipLaunchKernelGGL(ogb::k_og_block_sum, dim3(n_blocks), dim3(256), 0, 0, (const uint32_t*)(cnt_base + 1), n_cells, d_bsum);
+        HIP_CHECK(hipGetLastError());
+        std::vector<uint32_t> glob(glob_cap + 2u), bsum(n_blocks);
+        HIP_CHECK(hipMemcpy(glob.data(), d_glob, glob.size() * 4, hipMemcpyDeviceToHost));
+        const uint32_t n_global = glob[0];
+        hdr.n_global = n_global;
+        if (n_global > max_global) {   // (enabled = 0, as the host builder)
+            cleanup();
+            return false;
+        }
+        HIP_CHECK(hipMemcpy(bsum.data(), d_bsum, (size_t)n_blocks * 4, hipMemcpyDeviceToHost));
+        uint64_t run = n_global;
+        for (uint32_t b = 0; b < n_blocks; ++b) {   // exclusive prefix of the block sums, 64-bit
+            const uint32_t v = bsum[b];
+            if (run > 0xffffffffull) break;
+            bsum[b] = (uint32_t)run;
+            run += v;
+        }
+        const uint64_t total = run;
+        if (total > 0xffffffffull || bytes_used + (double)off_bytes + 8.0 * (double)total > budget) {
+            cleanup();
+            return false;
+        }
+        HIP_CHECK(hipMemcpy(d_bsum, bsum.data(), (size_t)n_blocks * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(ogb::k_og_block_scan, dim3(n_blocks), dim3(256), 0, 0, cnt_base + 1, n_cells, (const uint32_t*)d_bsum);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMalloc((void**)&d_refs, std::max<uint64_t>(1, total) * 8));
+        phase("scan");
+        if (n_global) {   // the global block in front: ascending primitive, bound 0 (as the host builder)
+            std::vector<uint32_t> g(glob.begin() + 2, glob.begin() + 2 + n_global);
+            std::sort(g.begin(), g.end());
+            std::vector<uint2> front(n_global);
+            for (uint32_t i = 0; i < n_global; ++i) front[i] = make_uint2(words[g[i]], 0u);
+            HIP_CHECK(hipMemcpy(d_refs, front.data(), (size_t)n_global * 8, hipMemcpyHostToDevice));
+        }
+        hipLaunchKernelGGL((ogb::k_og_raster<1>), pg, dim3(256), 0, 0, G, d_geom, d_words, n_prims, cnt_base + 1, d_refs, d_glob + 2,
+                           d_glob, glob_cap);
+        HIP_CHECK(hipGetLastError());
+        phase("fill");
+        HIP_CHECK(hipMemcpy(cnt_base, &n_global, 4, hipMemcpyHostToDevice));   // word 0: where cell 0 starts
+        hipLaunchKernelGGL(ogb::k_og_sort, dim3((uint32_t)((n_cells + 255) / 256)), dim3(256), 0, 0, (const uint32_t*)cnt_base, n_cells,
+                           d_refs, d_glob + 1);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(&hdr.max_cell_refs, d_glob + 1, 4, hipMemcpyDeviceToHost));   // (also the synchronisation point)
+        phase("sort");
+        (void)hipFree(d_glob);
+        (void)hipFree(d_bsum);
+        d_glob = d_bsum = nullptr;
+        s.allocations.push_back(cnt_base);
+        s.allocations.push_back(d_refs);
+        const double bytes = (double)off_bytes + 8.0 * (double)std::max<uint64_t>(1, total);
+        s.info.device_bytes += (uint64_t)bytes;
+        bytes_used += bytes;
+        hdr.n_refs = total;
+        hdr.enabled = 1;
+        out.cell_off = cnt_base;
+        out.refs = d_refs;
+        out.res = hdr.res;
+        out.n_global = n_global;
+        out.half_res = 0.5f * (float)hdr.res;
+        out.kind = hdr.kind;
+        memcpy(out.axis_u, hdr.axis_u, 12);
+        memcpy(out.axis_v, hdr.axis_v, 12);
+        memcpy(out.axis_w, hdr.axis_w, 12);
+        out.u0 = hdr.u0;
+        out.v0 = hdr.v0;
+        out.cells_per_unit = hdr.cells_per_unit;
+        hdr_out = hdr;
+        return true;
+    } catch (const GpuError&) {
+        cleanup();
+        memset(&out, 0, sizeof out);
+        return false;
+    }
+}
+
 // Copy a prepared scene to `device`.
 void scene_upload(const pt_prep& P, int device, pt_scene& s) {
     select_device(device);
@@ -1011,6 +1191,63 @@ void scene_upload(const pt_prep& P, int device, pt_scene& s) {
         out.v0 = g.v0;
         out.cells_per_unit = g.cells_per_unit;
     };
+    if (P.device_grids) {   // built here, on this device (a prep is shared by the devices of a multi-GPU host: each builds its own)
+        auto t_grid = std::chrono::steady_clock::now();
+        memset(&D.cam_grid, 0, sizeof D.cam_grid);
+        std::vector<DevGrid> lgrids(P.lights.size());
+        for (auto& g : lgrids) memset(&g, 0, sizeof g);
+        s.grid_headers.assign(1 + P.lights.size(), pth_origin_grid{});
+        s.host_light_grids.clear();
+        const uint32_t n_prims = D.n_prims;
+        float* d_geom = nullptr;
+        uint32_t* d_words = nullptr;
+        double used = 0;
+        if ((P.cam_job.valid || !P.light_jobs.empty()) && n_prims > 0 &&
+            hipMalloc((void**)&d_geom, P.og_geom.size() * 4) == hipSuccess && hipMalloc((void**)&d_words, P.og_words.size() * 4) == hipSuccess) {
+            HIP_CHECK(hipMemcpy(d_geom, P.og_geom.data(), P.og_geom.size() * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(d_words, P.og_words.data(), P.og_words.size() * 4, hipMemcpyHostToDevice));
+            if (device_grid_build(s, P.cam_job, d_geom, d_words, n_prims, P.og_words, used, P.og_budget, D.cam_grid, s.grid_headers[0])) {
+                s.info.cam_grid_res = s.grid_headers[0].res;
+                s.info.grid_refs += s.grid_headers[0].n_refs;
+            }
+            // the lights: all or none (the shadow queue is consumed by ONE kernel)
+            bool all = P.all_lights_gridded && P.light_jobs.size() == P.lights.size();
+            const size_t mark = s.allocations.size();
+            const uint64_t bytes_mark = s.info.device_bytes;
+            uint64_t light_refs = 0;
+            for (size_t i = 0; i < P.light_jobs.size() && all; ++i) {
+                if (!device_grid_build(s, P.light_jobs[i], d_geom, d_words, n_prims, P.og_words, used, P.og_budget, lgrids[i], s.grid_headers[1 + i]))
+                    all = false;
+                else {
+                    light_refs += s.grid_headers[1 + i].n_refs;
+                    if (lgrids[i].kind != 0) s.ortho_light_grids = true;
+                }
+            }
+            if (!all) {   // drop whatever light grids were built
+                for (size_t k = mark; k < s.allocations.size(); ++k) (void)hipFree(s.allocations[k]);
+                s.allocations.resize(mark);
+                s.info.device_bytes = bytes_mark;
+                for (auto& g : lgrids) memset(&g, 0, sizeof g);
+                for (size_t i = 1; i < s.grid_headers.size(); ++i) s.grid_headers[i] = pth_origin_grid{};
+                s.ortho_light_grids = false;
+                light_refs = 0;
+            }
+            D.all_lights_gridded = all ? 1u : 0u;
+            s.info.light_grids = all ? (uint32_t)P.lights.size() : 0u;
+            s.info.grid_refs += light_refs;
+        } else {
+            (void)hipGetLastError();
+            D.all_lights_gridded = (P.lights.empty() && P.all_lights_gridded) ? 1u : 0u;   // (no lights at all: vacuously)
+            s.info.light_grids = 0;
+        }
+        if (d_geom) (void)hipFree(d_geom);
+        if (d_words) (void)hipFree(d_words);
+        s.host_light_grids = lgrids;
+        D.light_grids = s.upload(lgrids.data(), lgrids.size());
+        s.info.grid_build_seconds += std::chrono::duration<float>(std::chrono::steady_clock::now() - t_grid).count();
+        s.info.upload_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_up).count() - s.info.grid_build_seconds;
+        return;
+    }
     // The grids are optional: a device that cannot hold them renders through the KD-tree (the light grids go first,
     // then the camera grid) instead of failing the scene.
     auto drop_allocations_from = [&](size_t mark, uint64_t bytes_mark) {
@@ -2099,6 +2336,28 @@ int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint
             memcpy(&o.v, &rest[i].z, 4);
             if (sphere) o.u = o.v = 0.f;
         }
+    });
+}
+
+int pt_scene_grid_header(const pt_scene* scene, uint32_t which, pth_origin_grid* out) {
+    return guarded([&] {
+        if (!scene || !out) fail(PT_ERR_INVALID, "pt_scene_grid_header: null argument");
+        memset(out, 0, sizeof *out);
+        if (which < scene->grid_headers.size()) *out = scene->grid_headers[which];
+        out->cell_off = nullptr;
+        out->refs = nullptr;
+    });
+}
+
+int pt_scene_grid_copy(const pt_scene* scene, uint32_t which, uint32_t* cell_off, pth_grid_ref* refs) {
+    return guarded([&] {
+        if (!scene || !cell_off || !refs) fail(PT_ERR_INVALID, "pt_scene_grid_copy: null argument");
+        if (which >= scene->grid_headers.size() || !scene->grid_headers[which].enabled) fail(PT_ERR_INVALID, "pt_scene_grid_copy: no such grid");
+        const pth_origin_grid& h = scene->grid_headers[which];
+        const DevGrid& g = which == 0 ? scene->dev.cam_grid : scene->host_light_grids[which - 1];
+        HIP_CHECK(hipSetDevice(scene->device));
+        HIP_CHECK(hipMemcpy(cell_off, g.cell_off, (h.n_cells + 1) * 4, hipMemcpyDeviceToHost));
+        if (h.n_refs) HIP_CHECK(hipMemcpy(refs, g.refs, h.n_refs * 8, hipMemcpyDeviceToHost));
     });
 }
 

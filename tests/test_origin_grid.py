@@ -170,3 +170,65 @@ def test_grid_rejects_bad_input(pta, scene_cache):
     v = scene.desc.contents.triangles
     g2 = pta.OriginGrid(scene, [v[0], v[1], v[2]])
     assert (not g2.enabled) or g2.n_global >= 1
+
+
+# ---------------------------------------------------------------------------------------------
+# The grids the DEVICE builds (csrc/pt_grid_build.h): the same lists as the host builder's, byte for byte (both compile
+# host/og_raster.h), and conservative in their own right.
+# ---------------------------------------------------------------------------------------------
+def _host_twin(pta, scene, which, res):
+    """The host-built grid with the parameters pt_scene_create derives for the device-built one."""
+    d = scene.desc.contents
+    if which == 0:
+        m = np.array(list(d.camera.transform), np.float64).reshape(4, 4)[:3, :3]
+        fro = float(np.sqrt((m * m).sum()))
+        return pta.OriginGrid(scene, camera_origin(scene), res, 0.0, np.float32(fro * 1.001))
+    light = d.lights[which - 1]
+    vec = np.array(list(light.vec), np.float32)
+    if light.kind == pta.PT_LIGHT_POINT:
+        return pta.OriginGrid(scene, vec, res, np.float32(1.05e-5) * np.float32(1.5), np.float32(1.001))
+    return pta.OriginGrid(scene, None, res, direction=(np.float32(-1.0) * vec))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MESH_SCENES + SPHERE_SCENES)
+def test_device_built_grids_equal_the_host_builders(pta, oracle, scene_cache, gpu_scene_cache, name):
+    scene, g = scene_cache(name), gpu_scene_cache(name)
+    info = g.info().as_dict()
+    assert info["cam_grid_res"] > 0 and info["light_grids"] == scene.n_lights
+    n_refs = 0
+    for which in range(1 + scene.n_lights):
+        dev = pta.OriginGrid.from_device(g, which)
+        assert dev.enabled
+        host = _host_twin(pta, scene, which, dev.res)
+        assert host.enabled and host.res == dev.res and host.n_global == dev.n_global and host.n_refs == dev.n_refs
+        assert np.array_equal(host.cell_off, dev.cell_off)
+        assert np.array_equal(host.ref_prim[:host.n_refs], dev.ref_prim[:dev.n_refs])
+        assert np.array_equal(host.ref_mindist[:host.n_refs].view(np.uint32), dev.ref_mindist[:dev.n_refs].view(np.uint32))
+        assert int(host.c.max_cell_refs) == int(dev.c.max_cell_refs)
+        n_refs += dev.n_refs
+        host.close()
+    assert n_refs == info["grid_refs"]
+    # ... and the conservativeness check of the camera grid on the device-built lists themselves
+    osc = oracle.OracleScene(scene.desc, oracle.PTO_BRUTE_FORCE)
+    prof = pta.Profile.make(256, 256, 4, 2)
+    rays = primary_rays(osc, prof, 800, seed=21)
+    hits, counts = osc.trace_all(rays, 16)
+    cam = pta.OriginGrid.from_device(g, 0)
+    assert check_rays(cam, rays, rays[:, 3:], hits, counts, origin=camera_origin(scene)) > 150
+
+
+@pytest.mark.gpu
+def test_device_built_grids_of_the_generated_scene(pta):
+    """The 30 k-triangle stand-in (opaque and translucent): device == host, camera and light grid."""
+    for flags in (0, 5):
+        scene = pta.HostScene.generate_ps5(30000, seed=0, flags=flags)
+        g = pta.GpuScene(scene)
+        for which in (0, 1):
+            dev = pta.OriginGrid.from_device(g, which)
+            host = _host_twin(pta, scene, which, dev.res)
+            assert dev.enabled and host.enabled and host.n_refs == dev.n_refs and host.n_global == dev.n_global
+            assert np.array_equal(host.cell_off, dev.cell_off)
+            assert np.array_equal(host.ref_prim[:host.n_refs], dev.ref_prim[:dev.n_refs])
+            assert np.array_equal(host.ref_mindist[:host.n_refs].view(np.uint32), dev.ref_mindist[:dev.n_refs].view(np.uint32))
+            host.close()
