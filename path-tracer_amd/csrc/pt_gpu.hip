@@ -473,6 +473,14 @@ struct pt_scene {
     std::vector<uint32_t> host_prim_entry;
     std::vector<pth_origin_grid> grid_headers;   // device-built grids: [0] camera, [1 + i] light i (enabled = 0: none)
     std::vector<DevGrid> host_light_grids;
+    struct BuiltGrids {   // what grids_on_device() produced for this scene (possibly while the KD-tree was still being built)
+        bool done = false, all_lights = false, ortho = false;
+        DevGrid cam{};
+        std::vector<DevGrid> lights;
+        uint32_t cam_res = 0, light_grids = 0;
+        uint64_t refs = 0, bytes = 0;
+        float seconds = 0.f;
+    } built;
     mutable pt_timing timing{};
     mutable pt_counters counters{};
     mutable DeviceBuffer accum_scratch, counter_buf, staging_buf;
@@ -569,7 +577,11 @@ struct pt_prep {
 
 namespace {
 
-void prep_create(const pt_scene_desc& d, pt_prep& P) {
+void grids_on_device(const pt_prep& P, pt_scene& s);
+
+// `early` / `early_device`: the scene this prep is made for, when there is exactly one (pt_scene_create): its origin grids
+// are then built on the device by the grid thread WHILE the KD-tree is being built on the host.
+void prep_create(const pt_scene_desc& d, pt_prep& P, pt_scene* early = nullptr, int early_device = -1) {
     const bool dbg_setup = getenv("PT_DEBUG_SETUP") != nullptr;
     auto t_sec = std::chrono::steady_clock::now();
     auto section = [&](const char* name) {
@@ -600,11 +612,128 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
         }
     }
 
+    // ---- per-primitive arrays
+    uint64_t n_prims = pth_prim_count(&d);
+    std::vector<float4>&attr = P.attr, &pos = P.pos;
+    attr.resize(n_prims * 4);
+    pos.resize(n_prims * 3);
+    P.og_geom.resize(n_prims * 9);
+    P.og_words.resize(n_prims);
+    P.model_mat.resize(d.n_models);
+    bool translucent = false;
+    uint64_t prim = 0;
+    for (uint32_t m = 0; m < d.n_models; ++m) {
+        const pt_model& mo = d.models[m];
+        P.model_mat[m] = d.materials[mo.material];
+        if (P.model_mat[m].opacity != 1.0f || P.model_mat[m].tex_opacity >= 0) translucent = true;
+        float mbits;
+        memcpy(&mbits, &m, 4);
+        if (mo.kind == PT_MODEL_MESH) {
+            for (uint32_t t = 0; t < mo.tri_count; ++t, ++prim) {
+                const float* v = d.triangles + (size_t)(mo.tri_first + t) * 24;
+                const float *a = v, *b = v + 8, *c = v + 16;
+                attr[prim * 4 + 0] = make_float4(a[3], a[4], a[5], a[6]);
+                attr[prim * 4 + 1] = make_float4(b[3], b[4], b[5], a[7]);
+                attr[prim * 4 + 2] = make_float4(c[3], c[4], c[5], b[6]);
+                attr[prim * 4 + 3] = make_float4(b[7], c[6], c[7], mbits);
+                float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+                float e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+                uint32_t pid = (uint32_t)prim;
+                float pbits;
+                memcpy(&pbits, &pid, 4);
+                pos[prim * 3 + 0] = make_float4(a[0], a[1], a[2], pbits);
+                pos[prim * 3 + 1] = make_float4(e1[0], e1[1], e1[2], e2[0]);
+                pos[prim * 3 + 2] = make_float4(e2[1], e2[2], 0.f, 0.f);
+                float* og = &P.og_geom[prim * 9];
+                og[0] = a[0]; og[1] = a[1]; og[2] = a[2];
+                og[3] = b[0]; og[4] = b[1]; og[5] = b[2];
+                og[6] = c[0]; og[7] = c[1]; og[8] = c[2];
+                P.og_words[prim] = pid;
+            }
+        } else {
+            attr[prim * 4 + 0] = make_float4(mo.center[0], mo.center[1], mo.center[2], mo.radius);
+            attr[prim * 4 + 1] = attr[prim * 4 + 2] = make_float4(0, 0, 0, 0);
+            attr[prim * 4 + 3] = make_float4(0, 0, 0, mbits);
+            uint32_t pid = (uint32_t)prim | PT_PRIM_SPHERE;
+            float pbits;
+            memcpy(&pbits, &pid, 4);
+            pos[prim * 3 + 0] = make_float4(mo.center[0], mo.center[1], mo.center[2], pbits);
+            pos[prim * 3 + 1] = make_float4(mo.radius, 0, 0, 0);
+            pos[prim * 3 + 2] = make_float4(0, 0, 0, 0);
+            float* og = &P.og_geom[prim * 9];
+            og[0] = mo.center[0]; og[1] = mo.center[1]; og[2] = mo.center[2]; og[3] = mo.radius;
+            og[4] = og[5] = og[6] = og[7] = og[8] = 0.f;
+            P.og_words[prim] = pid;
+            ++prim;
+        }
+    }
+    // ---- kdtree-ray's slab test (scene_slab, pt_integrator.h): the exact bounding box of the scene - the union of
+    // Model::bound() (model.rs:76-86: the positions' bounds for a mesh, centre -+ radius for a sphere) - and the mark
+    // on every primitive that comes close to one of its EDGES.  Only a ray that clips an edge of the box within the
+    // rounding of the test (~1e-7 of its length) can fail it while hitting something, and whatever it hits then lies
+    // within that distance (plus the slop of the intersection tests) of the edge.  delta = 1e-4 x (the largest distance a
+    // ray of this scene can cover: the box diagonal, or from the camera to its far corner) is a hundred times that; a
+    // primitive within delta of an edge has its own bounds within delta of the two faces that meet there.
+    {
+        DevScene& D = P.dev;
+        for (int a = 0; a < 3; ++a) {
+            D.slab_min[a] = INFINITY;
+            D.slab_max[a] = -INFINITY;
+        }
+        std::vector<float> pmn(n_prims * 3), pmx(n_prims * 3);
+        uint64_t q = 0;
+        for (uint32_t m = 0; m < d.n_models; ++m) {
+            const pt_model& mo = d.models[m];
+            const uint32_t cnt = mo.kind == PT_MODEL_MESH ? mo.tri_count : 1u;
+            for (uint32_t t = 0; t < cnt; ++t, ++q) {
+                for (int a = 0; a < 3; ++a) {
+                    float lo, hi;
+                    if (mo.kind == PT_MODEL_MESH) {
+                        const float* v = d.triangles + (size_t)(mo.tri_first + t) * 24;
+                        lo = fminf(fminf(v[a], v[8 + a]), v[16 + a]);
+                        hi = fmaxf(fmaxf(v[a], v[8 + a]), v[16 + a]);
+                    } else {
+                        lo = mo.center[a] - mo.radius;
+                        hi = mo.center[a] + mo.radius;
+                    }
+                    pmn[q * 3 + a] = lo;
+                    pmx[q * 3 + a] = hi;
+                    D.slab_min[a] = fminf(D.slab_min[a], lo);
+                    D.slab_max[a] = fmaxf(D.slab_max[a], hi);
+                }
+            }
+        }
+        double diag2 = 0, cam2 = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double w = (double)D.slab_max[a] - D.slab_min[a], c = d.camera.transform[12 + a];
+            const double far = std::max(std::fabs(c - D.slab_min[a]), std::fabs(c - D.slab_max[a]));
+            diag2 += w * w;
+            cam2 += far * far;
+        }
+        const double reach = std::sqrt(std::max(diag2, cam2));
+        const float delta = std::isfinite(reach) ? (float)(1e-4 * reach) : INFINITY;
+        if (n_prims >= (1ull << 28)) fail(PT_ERR_UNSUPPORTED, "more than 2^28 primitives");   // (pack_hit's index bits)
+        uint64_t marked = 0;
+        for (uint64_t k = 0; k < n_prims; ++k) {
+            int near_faces = 0;
+            for (int a = 0; a < 3; ++a)
+                if (!(pmn[k * 3 + a] > D.slab_min[a] + delta) || !(pmx[k * 3 + a] < D.slab_max[a] - delta)) ++near_faces;
+            if (near_faces >= 2) {
+                uint32_t w;
+                memcpy(&w, &pos[k * 3].w, 4);
+                w |= PT_PRIM_EDGE;
+                memcpy(&pos[k * 3].w, &w, 4);
+                ++marked;
+            }
+        }
+        P.info.n_edge_prims = (uint32_t)std::min<uint64_t>(marked, 0xffffffffu);
+    }
+    section("primitive arrays, edge marks");
     const uint64_t n_prims_early = pth_prim_count(&d);
     // ---- origin grids (host/origin_grid.cpp, csrc/pt_grid.h): camera rays, shadow rays of point lights.  They depend on the
     // scene description only, not on the KD-tree: built on a thread of their own BESIDE the KD build (both are seconds of
     // multi-threaded host work; setup of config 3: 3.2 -> 2.3 s).
-    auto build_grids = [&P, &d, n_prims_early]() {
+    auto build_grids = [&P, &d, n_prims_early, early, early_device]() {
         const uint64_t n_prims = n_prims_early;
         const float* M = d.camera.transform;
         DevScene& D = P.dev;
@@ -667,6 +796,13 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
             D.all_lights_gridded = all ? 1u : 0u;
             D.light_grid_max_normal2 = max_normal * max_normal;
             P.info.grid_build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_grid).count();
+            if (early) {
+                select_device(early_device);
+                int cur = 0;
+                HIP_CHECK(hipGetDevice(&cur));
+                early->device = cur;
+                grids_on_device(P, *early);
+            }
             return;
         }
         // (the camera grid on a thread of its own beside the light grids: every grid is its own count / scan / fill / sort)
@@ -731,124 +867,7 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
     std::unique_ptr<pth_kdtree, void (*)(pth_kdtree*)> kd_guard(&kd, pth_kd_free);
     if (kd.depth >= PT_KD_STACK) fail(PT_ERR_UNSUPPORTED, "KD-tree depth %u exceeds the traversal stack", kd.depth);
 
-    section("validate + KD build");
-    // ---- per-primitive arrays
-    uint64_t n_prims = pth_prim_count(&d);
-    std::vector<float4>&attr = P.attr, &pos = P.pos;
-    attr.resize(n_prims * 4);
-    pos.resize(n_prims * 3);
-    P.og_geom.resize(n_prims * 9);
-    P.og_words.resize(n_prims);
-    P.model_mat.resize(d.n_models);
-    bool translucent = false;
-    uint64_t prim = 0;
-    for (uint32_t m = 0; m < d.n_models; ++m) {
-        const pt_model& mo = d.models[m];
-        P.model_mat[m] = d.materials[mo.material];
-        if (P.model_mat[m].opacity != 1.0f || P.model_mat[m].tex_opacity >= 0) translucent = true;
-        float mbits;
-        memcpy(&mbits, &m, 4);
-        if (mo.kind == PT_MODEL_MESH) {
-            for (uint32_t t = 0; t < mo.tri_count; ++t, ++prim) {
-                const float* v = d.triangles + (size_t)(mo.tri_first + t) * 24;
-                const float *a = v, *b = v + 8, *c = v + 16;
-                attr[prim * 4 + 0] = make_float4(a[3], a[4], a[5], a[6]);
-                attr[prim * 4 + 1] = make_float4(b[3], b[4], b[5], a[7]);
-                attr[prim * 4 + 2] = make_float4(c[3], c[4], c[5], b[6]);
-                attr[prim * 4 + 3] = make_float4(b[7], c[6], c[7], mbits);
-                float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-                float e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
-                uint32_t pid = (uint32_t)prim;
-                float pbits;
-                memcpy(&pbits, &pid, 4);
-                pos[prim * 3 + 0] = make_float4(a[0], a[1], a[2], pbits);
-                pos[prim * 3 + 1] = make_float4(e1[0], e1[1], e1[2], e2[0]);
-                pos[prim * 3 + 2] = make_float4(e2[1], e2[2], 0.f, 0.f);
-                float* og = &P.og_geom[prim * 9];
-                og[0] = a[0]; og[1] = a[1]; og[2] = a[2];
-                og[3] = b[0]; og[4] = b[1]; og[5] = b[2];
-                og[6] = c[0]; og[7] = c[1]; og[8] = c[2];
-                P.og_words[prim] = pid;
-            }
-        } else {
-            attr[prim * 4 + 0] = make_float4(mo.center[0], mo.center[1], mo.center[2], mo.radius);
-            attr[prim * 4 + 1] = attr[prim * 4 + 2] = make_float4(0, 0, 0, 0);
-            attr[prim * 4 + 3] = make_float4(0, 0, 0, mbits);
-            uint32_t pid = (uint32_t)prim | PT_PRIM_SPHERE;
-            float pbits;
-            memcpy(&pbits, &pid, 4);
-            pos[prim * 3 + 0] = make_float4(mo.center[0], mo.center[1], mo.center[2], pbits);
-            pos[prim * 3 + 1] = make_float4(mo.radius, 0, 0, 0);
-            pos[prim * 3 + 2] = make_float4(0, 0, 0, 0);
-            float* og = &P.og_geom[prim * 9];
-            og[0] = mo.center[0]; og[1] = mo.center[1]; og[2] = mo.center[2]; og[3] = mo.radius;
-            og[4] = og[5] = og[6] = og[7] = og[8] = 0.f;
-            P.og_words[prim] = pid;
-            ++prim;
-        }
-    }
-    section("primitive arrays");
-    // ---- kdtree-ray's slab test (scene_slab, pt_integrator.h): the exact bounding box of the scene - the union of
-    // Model::bound() (model.rs:76-86: the positions' bounds for a mesh, centre -+ radius for a sphere) - and the mark
-    // on every primitive that comes close to one of its EDGES.  Only a ray that clips an edge of the box within the
-    // rounding of the test (~1e-7 of its length) can fail it while hitting something, and whatever it hits then lies
-    // within that distance (plus the slop of the intersection tests) of the edge.  delta = 1e-4 x (the largest distance a
-    // ray of this scene can cover: the box diagonal, or from the camera to its far corner) is a hundred times that; a
-    // primitive within delta of an edge has its own bounds within delta of the two faces that meet there.
-    {
-        DevScene& D = P.dev;
-        for (int a = 0; a < 3; ++a) {
-            D.slab_min[a] = INFINITY;
-            D.slab_max[a] = -INFINITY;
-        }
-        std::vector<float> pmn(n_prims * 3), pmx(n_prims * 3);
-        uint64_t q = 0;
-        for (uint32_t m = 0; m < d.n_models; ++m) {
-            const pt_model& mo = d.models[m];
-            const uint32_t cnt = mo.kind == PT_MODEL_MESH ? mo.tri_count : 1u;
-            for (uint32_t t = 0; t < cnt; ++t, ++q) {
-                for (int a = 0; a < 3; ++a) {
-                    float lo, hi;
-                    if (mo.kind == PT_MODEL_MESH) {
-                        const float* v = d.triangles + (size_t)(mo.tri_first + t) * 24;
-                        lo = fminf(fminf(v[a], v[8 + a]), v[16 + a]);
-                        hi = fmaxf(fmaxf(v[a], v[8 + a]), v[16 + a]);
-                    } else {
-                        lo = mo.center[a] - mo.radius;
-                        hi = mo.center[a] + mo.radius;
-                    }
-                    pmn[q * 3 + a] = lo;
-                    pmx[q * 3 + a] = hi;
-                    D.slab_min[a] = fminf(D.slab_min[a], lo);
-                    D.slab_max[a] = fmaxf(D.slab_max[a], hi);
-                }
-            }
-        }
-        double diag2 = 0, cam2 = 0;
-        for (int a = 0; a < 3; ++a) {
-            const double w = (double)D.slab_max[a] - D.slab_min[a], c = d.camera.transform[12 + a];
-            const double far = std::max(std::fabs(c - D.slab_min[a]), std::fabs(c - D.slab_max[a]));
-            diag2 += w * w;
-            cam2 += far * far;
-        }
-        const double reach = std::sqrt(std::max(diag2, cam2));
-        const float delta = std::isfinite(reach) ? (float)(1e-4 * reach) : INFINITY;
-        if (n_prims >= (1ull << 28)) fail(PT_ERR_UNSUPPORTED, "more than 2^28 primitives");   // (pack_hit's index bits)
-        uint64_t marked = 0;
-        for (uint64_t k = 0; k < n_prims; ++k) {
-            int near_faces = 0;
-            for (int a = 0; a < 3; ++a)
-                if (!(pmn[k * 3 + a] > D.slab_min[a] + delta) || !(pmx[k * 3 + a] < D.slab_max[a] - delta)) ++near_faces;
-            if (near_faces >= 2) {
-                uint32_t w;
-                memcpy(&w, &pos[k * 3].w, 4);
-                w |= PT_PRIM_EDGE;
-                memcpy(&pos[k * 3].w, &w, 4);
-                ++marked;
-            }
-        }
-        P.info.n_edge_prims = (uint32_t)std::min<uint64_t>(marked, 0xffffffffu);
-    }
+    section("KD build");
     section("slab box + edge marks");
     // leaf records in leaf-reference order
     P.leaf.resize(kd.n_refs * 3);
@@ -1034,7 +1053,8 @@ void prep_create(const pt_scene_desc& d, pt_prep& P) {
 // the byte budget of the scene's grids exceeded, or the device out of memory: the casts it would have served take the
 // KD-tree.  On success the two arrays belong to the scene (s.allocations).
 bool device_grid_build(pt_scene& s, const pt_prep::GridJob& job, const float* d_geom, const uint32_t* d_words, uint32_t n_prims,
-                       const std::vector<uint32_t>& words, double& bytes_used, double budget, DevGrid& out, pth_origin_grid& hdr_out) {
+                       const std::vector<uint32_t>& words, double& bytes_used, double budget, DevGrid& out, pth_origin_grid& hdr_out,
+                       uint64_t& dev_bytes) {
     memset(&out, 0, sizeof out);
     if (!job.valid || n_prims == 0) return false;
     static const uint32_t max_global = [] {
@@ -1127,7 +1147,7 @@ bool device_grid_build(pt_scene& s, const pt_prep::GridJob& job, const float* d_
         s.allocations.push_back(cnt_base);
         s.allocations.push_back(d_refs);
         const double bytes = (double)off_bytes + 8.0 * (double)std::max<uint64_t>(1, total);
-        s.info.device_bytes += (uint64_t)bytes;
+        dev_bytes += (uint64_t)bytes;
         bytes_used += bytes;
         hdr.n_refs = total;
         hdr.enabled = 1;
@@ -1150,6 +1170,65 @@ bool device_grid_build(pt_scene& s, const pt_prep::GridJob& job, const float* d_
         memset(&out, 0, sizeof out);
         return false;
     }
+}
+
+// Every origin grid of the scene, built on the device the calling thread has selected, into s.built (the arrays go to
+// s.allocations).  Needs of the prep only what prep_create has ready BEFORE the KD build: the grid jobs and the
+// primitives' geometry - so pt_scene_create runs it on a thread of its own beside the KD build.
+void grids_on_device(const pt_prep& P, pt_scene& s) {
+    auto t_grid = std::chrono::steady_clock::now();
+    pt_scene::BuiltGrids& B = s.built;
+    const size_t n_lights = P.light_jobs.size();
+    B = pt_scene::BuiltGrids();
+    B.lights.assign(n_lights, DevGrid{});
+    for (auto& g : B.lights) memset(&g, 0, sizeof g);
+    memset(&B.cam, 0, sizeof B.cam);
+    s.grid_headers.assign(1 + std::max(n_lights, (size_t)0), pth_origin_grid{});
+    const uint32_t n_prims = (uint32_t)P.og_words.size();
+    float* d_geom = nullptr;
+    uint32_t* d_words = nullptr;
+    double used = 0;
+    if ((P.cam_job.valid || n_lights) && n_prims > 0 && hipMalloc((void**)&d_geom, P.og_geom.size() * 4) == hipSuccess &&
+        hipMalloc((void**)&d_words, P.og_words.size() * 4) == hipSuccess) {
+        bool copied = hipMemcpy(d_geom, P.og_geom.data(), P.og_geom.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                      hipMemcpy(d_words, P.og_words.data(), P.og_words.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        if (copied && device_grid_build(s, P.cam_job, d_geom, d_words, n_prims, P.og_words, used, P.og_budget, B.cam, s.grid_headers[0], B.bytes)) {
+            B.cam_res = s.grid_headers[0].res;
+            B.refs += s.grid_headers[0].n_refs;
+        }
+        // the lights: all or none (the shadow queue is consumed by ONE kernel)
+        bool all = copied && P.all_lights_gridded;
+        const size_t mark = s.allocations.size();
+        const uint64_t bytes_mark = B.bytes;
+        uint64_t light_refs = 0;
+        for (size_t i = 0; i < n_lights && all; ++i) {
+            if (!device_grid_build(s, P.light_jobs[i], d_geom, d_words, n_prims, P.og_words, used, P.og_budget, B.lights[i], s.grid_headers[1 + i], B.bytes))
+                all = false;
+            else {
+                light_refs += s.grid_headers[1 + i].n_refs;
+                if (B.lights[i].kind != 0) B.ortho = true;
+            }
+        }
+        if (!all) {   // drop whatever light grids were built
+            for (size_t k = mark; k < s.allocations.size(); ++k) (void)hipFree(s.allocations[k]);
+            s.allocations.resize(mark);
+            B.bytes = bytes_mark;
+            for (auto& g : B.lights) memset(&g, 0, sizeof g);
+            for (size_t i = 1; i < s.grid_headers.size(); ++i) s.grid_headers[i] = pth_origin_grid{};
+            B.ortho = false;
+            light_refs = 0;
+        }
+        B.all_lights = all;
+        B.light_grids = all ? (uint32_t)n_lights : 0u;
+        B.refs += light_refs;
+    } else {
+        (void)hipGetLastError();
+        B.all_lights = n_lights == 0 && P.all_lights_gridded;   // (no lights at all: vacuously)
+    }
+    if (d_geom) (void)hipFree(d_geom);
+    if (d_words) (void)hipFree(d_words);
+    B.seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_grid).count();
+    B.done = true;
 }
 
 // Copy a prepared scene to `device`.
@@ -1191,61 +1270,22 @@ void scene_upload(const pt_prep& P, int device, pt_scene& s) {
         out.v0 = g.v0;
         out.cells_per_unit = g.cells_per_unit;
     };
-    if (P.device_grids) {   // built here, on this device (a prep is shared by the devices of a multi-GPU host: each builds its own)
-        auto t_grid = std::chrono::steady_clock::now();
-        memset(&D.cam_grid, 0, sizeof D.cam_grid);
-        std::vector<DevGrid> lgrids(P.lights.size());
-        for (auto& g : lgrids) memset(&g, 0, sizeof g);
-        s.grid_headers.assign(1 + P.lights.size(), pth_origin_grid{});
-        s.host_light_grids.clear();
-        const uint32_t n_prims = D.n_prims;
-        float* d_geom = nullptr;
-        uint32_t* d_words = nullptr;
-        double used = 0;
-        if ((P.cam_job.valid || !P.light_jobs.empty()) && n_prims > 0 &&
-            hipMalloc((void**)&d_geom, P.og_geom.size() * 4) == hipSuccess && hipMalloc((void**)&d_words, P.og_words.size() * 4) == hipSuccess) {
-            HIP_CHECK(hipMemcpy(d_geom, P.og_geom.data(), P.og_geom.size() * 4, hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemcpy(d_words, P.og_words.data(), P.og_words.size() * 4, hipMemcpyHostToDevice));
-            if (device_grid_build(s, P.cam_job, d_geom, d_words, n_prims, P.og_words, used, P.og_budget, D.cam_grid, s.grid_headers[0])) {
-                s.info.cam_grid_res = s.grid_headers[0].res;
-                s.info.grid_refs += s.grid_headers[0].n_refs;
-            }
-            // the lights: all or none (the shadow queue is consumed by ONE kernel)
-            bool all = P.all_lights_gridded && P.light_jobs.size() == P.lights.size();
-            const size_t mark = s.allocations.size();
-            const uint64_t bytes_mark = s.info.device_bytes;
-            uint64_t light_refs = 0;
-            for (size_t i = 0; i < P.light_jobs.size() && all; ++i) {
-                if (!device_grid_build(s, P.light_jobs[i], d_geom, d_words, n_prims, P.og_words, used, P.og_budget, lgrids[i], s.grid_headers[1 + i]))
-                    all = false;
-                else {
-                    light_refs += s.grid_headers[1 + i].n_refs;
-                    if (lgrids[i].kind != 0) s.ortho_light_grids = true;
-                }
-            }
-            if (!all) {   // drop whatever light grids were built
-                for (size_t k = mark; k < s.allocations.size(); ++k) (void)hipFree(s.allocations[k]);
-                s.allocations.resize(mark);
-                s.info.device_bytes = bytes_mark;
-                for (auto& g : lgrids) memset(&g, 0, sizeof g);
-                for (size_t i = 1; i < s.grid_headers.size(); ++i) s.grid_headers[i] = pth_origin_grid{};
-                s.ortho_light_grids = false;
-                light_refs = 0;
-            }
-            D.all_lights_gridded = all ? 1u : 0u;
-            s.info.light_grids = all ? (uint32_t)P.lights.size() : 0u;
-            s.info.grid_refs += light_refs;
-        } else {
-            (void)hipGetLastError();
-            D.all_lights_gridded = (P.lights.empty() && P.all_lights_gridded) ? 1u : 0u;   // (no lights at all: vacuously)
-            s.info.light_grids = 0;
-        }
-        if (d_geom) (void)hipFree(d_geom);
-        if (d_words) (void)hipFree(d_words);
+    if (P.device_grids) {   // built on this device (a prep is shared by the devices of a multi-GPU host: each builds its own)
+        if (!s.built.done) grids_on_device(P, s);   // (pt_scene_create has them built beside the KD-tree already)
+        const pt_scene::BuiltGrids& B = s.built;
+        D.cam_grid = B.cam;
+        std::vector<DevGrid> lgrids = B.lights;
+        lgrids.resize(P.lights.size());
+        D.all_lights_gridded = B.all_lights ? 1u : 0u;
+        s.ortho_light_grids = B.ortho;
+        s.info.cam_grid_res = B.cam_res;
+        s.info.light_grids = B.light_grids;
+        s.info.grid_refs = B.refs;
+        s.info.device_bytes += B.bytes;
+        s.info.grid_build_seconds += B.seconds;
         s.host_light_grids = lgrids;
         D.light_grids = s.upload(lgrids.data(), lgrids.size());
-        s.info.grid_build_seconds += std::chrono::duration<float>(std::chrono::steady_clock::now() - t_grid).count();
-        s.info.upload_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_up).count() - s.info.grid_build_seconds;
+        s.info.upload_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_up).count();
         return;
     }
     // The grids are optional: a device that cannot hold them renders through the KD-tree (the light grids go first,
@@ -1924,8 +1964,8 @@ int pt_scene_create(const pt_scene_desc* desc, int device, pt_scene** out) {
     return guarded([&] {
         if (!desc || !out) fail(PT_ERR_INVALID, "pt_scene_create: null argument");
         pt_prep prep;
-        prep_create(*desc, prep);
         auto s = std::make_unique<pt_scene>();
+        prep_create(*desc, prep, s.get(), device);
         scene_upload(prep, device, *s);
         *out = s.release();
     });
