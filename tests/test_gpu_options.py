@@ -50,6 +50,8 @@ SETTINGS = [
     {"PT_TILE_ORDER": "morton"},
     {"PT_WF_ENTRY": "1"},                 # casts of bounces >= 1 start at their primitive's home node (entry lists)
     {"PT_WF_ENTRY": "1", "PT_OG": "0"},   # ... on the KD-only pipeline
+    {"PT_OG_HOST": "1"},                  # origin grids built by the host builder and uploaded (the round-2 path)
+    {"PT_KD_PAD": "1"},                   # KD-tree over fattened primitives (the oracle filter's padding)
     {"PT_OG_BUDGET_GIB": "0.02"},         # grid memory budget of 20 MB: a coarser camera grid, the light on the KD-tree
     {"PT_OG_BUDGET_GIB": "0.001"},        # ... of 1 MB: no grid fits
 ]
@@ -59,7 +61,7 @@ EXPECT_GRIDS = {"0.02": "512 0", "0.001": "0 0"}
 def run_child(extra):
     env = dict(os.environ)
     for k in list(env):
-        if k.startswith(("PT_WF_", "PT_OG", "PT_SHADE_", "PT_TILE_")):
+        if k.startswith(("PT_WF_", "PT_OG", "PT_SHADE_", "PT_TILE_", "PT_KD_")):
             del env[k]
     env.update(extra)
     code = CHILD % {"root": str(ROOT), "scene": str(ROOT / "tests/golden/scenes/alpha_transparency/scene.isf")}

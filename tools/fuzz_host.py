@@ -1,4 +1,4 @@
-"""Mutation fuzzing of the parsers that take untrusted bytes: ISF scene files, PNG textures, profile YAML, glTF / GLB.
+"""Mutation fuzzing of the parsers that take untrusted bytes: ISF scene files, PNG / JPEG textures, profile YAML, glTF / GLB.
 Every input must come back as a status code (PT_OK or an error with a message), never as a crash.  Meant to run
 against the sanitized host library:  bash tools/asan_host.sh builds it; or standalone:
 
@@ -15,6 +15,21 @@ golden = pathlib.Path(__file__).resolve().parent.parent / "tests" / "golden"
 scenes = sorted(golden.glob("scenes/*/scene.isf")) or sorted(golden.rglob("*.isf"))
 pngs = sorted(golden.rglob("*.png"))
 assert scenes and pngs, (len(scenes), len(pngs))
+# JPEG corpus: baseline + progressive, grey + 4:4:4 / 4:2:0 colour, with restart markers (PIL is the ENcoder only)
+import io
+import numpy as np
+from PIL import Image
+_r = np.random.default_rng(7)
+_img = np.clip(np.add.outer(np.arange(40) * 5, np.arange(56) * 3)[..., None] + _r.integers(0, 60, (40, 56, 3)), 0, 255).astype(np.uint8)
+jpegs = []
+for _mode, _kw in (("RGB", dict(subsampling=0)), ("RGB", dict(subsampling=2)), ("L", {}), ("RGB", dict(progressive=True)),
+                   ("RGB", dict(subsampling=2, restart_marker_blocks=2))):
+    _b = io.BytesIO()
+    try:
+        Image.fromarray(_img if _mode == "RGB" else _img[..., 0]).save(_b, "JPEG", quality=80, **_kw)
+    except TypeError:
+        continue
+    jpegs.append(_b.getvalue())
 # glTF corpus: the small scene of tests/test_convert.py as .gltf (base64 buffer) and as .glb
 sys.path.insert(0, str(golden.parent))
 import base64, json, struct
@@ -62,7 +77,7 @@ try:
             rc = L.pth_scene_load_isf(os.fsencode(str(d / "scene.isf")), C.byref(h))
             if rc == 0: L.pth_scene_free(h)
         elif which == 1:   # PNG
-            data = mutate(rng.choice(pngs).read_bytes())
+            data = mutate(rng.choice(jpegs) if it % 8 >= 4 else rng.choice(pngs).read_bytes())   # the decoder dispatches on the magic
             w, hh, px = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
             rc = L.pth_png_decode(data, len(data), rng.choice([1, 3]), C.byref(w), C.byref(hh), C.byref(px))
             if rc == 0: L.pth_free(px)
