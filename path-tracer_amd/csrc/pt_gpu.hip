@@ -488,8 +488,8 @@ struct pt_scene {
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
         DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid, deferred;
-        hipStream_t side = nullptr, side_rng = nullptr;
-        hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr;
+        hipStream_t side = nullptr, side_rng = nullptr, side_wide = nullptr;
+        hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr, ev_trace = nullptr, ev_wide = nullptr;
     };
     mutable WfPipe pipe;
     mutable int trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
@@ -504,10 +504,11 @@ struct pt_scene {
         (void)hipSetDevice(device);
         for (void* p : allocations) (void)hipFree(p);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {pipe.ev_shade, pipe.ev_shadow, pipe.ev_rng, pipe.ev_chunk})
+        for (hipEvent_t e : {pipe.ev_shade, pipe.ev_shadow, pipe.ev_rng, pipe.ev_chunk, pipe.ev_trace, pipe.ev_wide})
             if (e) (void)hipEventDestroy(e);
         if (pipe.side) (void)hipStreamDestroy(pipe.side);
         if (pipe.side_rng) (void)hipStreamDestroy(pipe.side_rng);
+        if (pipe.side_wide) (void)hipStreamDestroy(pipe.side_wide);
     }
     template <class T>
     const T* upload(const T* host, size_t count) {
@@ -1469,6 +1470,14 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         // later bounces (7.9 against 8.2 ms per 64 spp, MI355X, config 3)
         return (uint32_t)(e && *e ? atoi(e) : 0);
     }();
+    // The shade pass of bounces >= 1 runs beside k_wf_trace_wide (see the launch below).  Measured (MI355X, config 3;
+    // profiles/r03_experiments.txt item 6): frame 34.26 -> 34.14 ms, one shard of eight 5.85 -> 5.69 ms - the two kernels
+    // slow each other down (beside the 4 workgroups per CU of k_wf_trace_wide a SIMD has registers for one shade wavefront
+    // instead of four), so only part of the shorter one is hidden.
+    static const bool wf_split = [] {
+        const char* e = getenv("PT_WF_SPLIT");
+        return e && *e ? atoi(e) != 0 : true;
+    }();
     static const uint32_t wf_defer = [] {   // k_wf_trace: age (loop iterations) at which a cast leaves a drained wavefront
         const char* e = getenv("PT_WF_DEFER");
         return (uint32_t)(e && *e ? atoi(e) : 16);
@@ -1548,7 +1557,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       (!alpha || w.draws.try_ensure((size_t)cap * 4u)) &&   // RNG draw index of the alpha walk
                       (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u)) &&   // surfaces left to the KD-tree
                       // casts left to k_wf_trace_wide: at most one per lane in flight when the queue runs dry
-                      (alpha || !wf_defer || w.deferred.try_ensure((size_t)s.trace_blocks * WF_THREADS * 4u));
+                      // (4 B the queue index + 20 B the hit k_wf_trace_wide finds, when the shade pass is split)
+                      (alpha || !wf_defer || w.deferred.try_ensure((size_t)s.trace_blocks * WF_THREADS * 24u));
             if (ok) {
                 if (multi_chunk) s.wf_cap_ok = cap;   // (a frame that fits in one chunk says nothing about larger ones)
                 break;
@@ -1571,6 +1581,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             HIP_CHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_shade, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_shadow, hipEventDisableTiming));
+        }
+        if (wf_overlap && !w.side_wide) {
+            HIP_CHECK(hipStreamCreateWithFlags(&w.side_wide, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&w.ev_trace, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&w.ev_wide, hipEventDisableTiming));
         }
     }
     uint32_t blocks = tm.n_local_tiles * (o.tile_w * o.tile_h / 256u);
@@ -1712,8 +1727,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     } while (0)
 // k_wf_shade<ALPHA, COUNT, PRIMARY, GRID>
 #define PT_SHADE_ARGS                                                                                                         \
-    s.dev, W, d_tiles, (const float4*)q_in, (const uint4*)pipe.hits.p, (const uint4*)rng_planes, (const uint32_t*)pipe.draws.p, \
-        q_out, (float4*)pipe.shadow.p, (float4*)pipe.contrib.p, (float*)s.staging_buf.p, wctr, gctr
+    s.dev, W, d_tiles, (const float4*)q_in, shade_hits, (const uint4*)rng_planes, (const uint32_t*)pipe.draws.p, \
+        q_out, (float4*)pipe.shadow.p, (float4*)pipe.contrib.p, (float*)s.staging_buf.p, shade_list, wctr, gctr
 #define PT_LAUNCH_SHADE(A, C, P, G)                                                                                    \
     hipLaunchKernelGGL((k_wf_shade<A, C, P, G>), dim3(shade_grid), dim3(WF_SHADE_THREADS), 0, st_main, PT_SHADE_ARGS)
 #define PT_LAUNCH_SHADE_G(G)                                                   \
@@ -1734,6 +1749,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         else if (counting) PT_LAUNCH_SHADE(false, true, true, G);       \
         else PT_LAUNCH_SHADE(false, false, true, G);                    \
     } while (0)
+                    bool split_shade = false;
                     if (grid_mode < 2) {   // (grid_mode >= 2: k_wf_shade casts the camera rays itself)
                         stage_begin(1);
                         if (prim && use_cam_grid) {   // camera rays: one grid lookup instead of a KD walk (pt_grid_kernels.h)
@@ -1749,12 +1765,25 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             HIP_CHECK(hipGetLastError());
                         } else {
                             W.defer_age = (prim || alpha) ? 0u : wf_defer;
+                            // the hand-over list: queue indices, then (split shade pass) the plane of their hits
+                            const uint32_t list_cap = (uint32_t)s.trace_blocks * WF_THREADS;
+                            uint4* list_hits = (uint4*)((uint32_t*)pipe.deferred.p + list_cap);
+                            split_shade = wf_split && W.defer_age != 0u && pipe.side_wide != nullptr;
+                            W.split_deferred = split_shade ? list_cap : 0u;
                             PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
                                           (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (uint32_t*)pipe.deferred.p, wctr, gctr);
                             if (W.defer_age) {   // the casts the drained wavefronts handed over (pt_wavefront.h)
-                                if (counting) hipLaunchKernelGGL((k_wf_trace_wide<true>), dim3((uint32_t)s.n_cu * 4u), dim3(WF_THREADS), 0, st_main, s.dev, W, (const float4*)q_in, (uint4*)pipe.hits.p, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
-                                else hipLaunchKernelGGL((k_wf_trace_wide<false>), dim3((uint32_t)s.n_cu * 4u), dim3(WF_THREADS), 0, st_main, s.dev, W, (const float4*)q_in, (uint4*)pipe.hits.p, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
+                                // split shade pass: on a stream of its own, underneath k_wf_shade's pass over the queue
+                                hipStream_t st_wide = split_shade ? pipe.side_wide : st_main;
+                                uint4* wide_hits = split_shade ? list_hits : (uint4*)pipe.hits.p;
+                                if (split_shade) {
+                                    HIP_CHECK(hipEventRecord(pipe.ev_trace, st_main));
+                                    HIP_CHECK(hipStreamWaitEvent(st_wide, pipe.ev_trace, 0));
+                                }
+                                if (counting) hipLaunchKernelGGL((k_wf_trace_wide<true>), dim3((uint32_t)s.n_cu * 4u), dim3(WF_THREADS), 0, st_wide, s.dev, W, (const float4*)q_in, wide_hits, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
+                                else hipLaunchKernelGGL((k_wf_trace_wide<false>), dim3((uint32_t)s.n_cu * 4u), dim3(WF_THREADS), 0, st_wide, s.dev, W, (const float4*)q_in, wide_hits, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
                                 HIP_CHECK(hipGetLastError());
+                                if (split_shade) HIP_CHECK(hipEventRecord(pipe.ev_wide, st_wide));
                             }
                         }
                         stage_end();
@@ -1763,23 +1792,38 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     // shade(b) reads the colours shadow(b-1) patched and refills the shadow queue it consumed
                     if (st_shadow != st_main && b > 0) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
                     // (no more workgroups than the chunk has 256-entry steps)
-                    const uint32_t shade_grid = std::max(1u, std::min((uint32_t)s.n_cu * (prim ? shade_blocks_b0 : shade_blocks_later),
-                                                                      (W.n_items + WF_SHADE_THREADS - 1u) / WF_SHADE_THREADS));
+                    uint32_t shade_grid = std::max(1u, std::min((uint32_t)s.n_cu * (prim ? shade_blocks_b0 : shade_blocks_later),
+                                                                (W.n_items + WF_SHADE_THREADS - 1u) / WF_SHADE_THREADS));
                     if (timing && grid_mode >= 2) fused_marks.push_back(ev);
                     stage_begin(2);
                     // (+4: the variants with the orthographic branch for directional lights compiled in)
                     const bool dirl = s.ortho_light_grids;
-                    if (grid_mode == 3) {
-                        if (dirl) PT_LAUNCH_SHADE_P(7);
-                        else PT_LAUNCH_SHADE_P(3);
-                    } else if (grid_mode == 2) {
-                        if (dirl) PT_LAUNCH_SHADE_P(6);
-                        else PT_LAUNCH_SHADE_P(2);
-                    } else if (grid_mode == 1) {
-                        if (dirl) PT_LAUNCH_SHADE_G(5);
-                        else PT_LAUNCH_SHADE_G(1);
-                    } else {
-                        PT_LAUNCH_SHADE_G(0);
+                    const uint4* shade_hits = (const uint4*)pipe.hits.p;
+                    const uint32_t* shade_list = nullptr;
+                    auto launch_shade = [&]() {
+                        if (grid_mode == 3) {
+                            if (dirl) PT_LAUNCH_SHADE_P(7);
+                            else PT_LAUNCH_SHADE_P(3);
+                        } else if (grid_mode == 2) {
+                            if (dirl) PT_LAUNCH_SHADE_P(6);
+                            else PT_LAUNCH_SHADE_P(2);
+                        } else if (grid_mode == 1) {
+                            if (dirl) PT_LAUNCH_SHADE_G(5);
+                            else PT_LAUNCH_SHADE_G(1);
+                        } else {
+                            PT_LAUNCH_SHADE_G(0);
+                        }
+                        HIP_CHECK(hipGetLastError());
+                    };
+                    launch_shade();
+                    if (split_shade) {
+                        // ... and the casts that were with k_wf_trace_wide meanwhile: the hand-over list (at most one entry per
+                        // lane of the trace grid; usually a few thousand - a launch that finds an empty list returns)
+                        HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_wide, 0));
+                        shade_hits = (const uint4*)((const uint32_t*)pipe.deferred.p + W.split_deferred);
+                        shade_list = (const uint32_t*)pipe.deferred.p;
+                        shade_grid = std::min(shade_grid, (uint32_t)s.n_cu);
+                        launch_shade();
                     }
                     HIP_CHECK(hipGetLastError());
                     stage_end();

@@ -75,6 +75,9 @@ struct WfParams {
     uint32_t sort_octants;  // k_wf_shade: bit 0 - survivors of a workgroup step bucketed by direction octant; bit 1 - hits shaded in material order
     uint32_t defer_age;     // k_wf_trace, queue exhausted: casts older than this many loop iterations go to k_wf_trace_wide (0: never)
     uint32_t use_entry;     // the queues carry entry words (trav_enter): casts of bounces >= 1 start at their primitive's home node
+    uint32_t split_deferred;   // != 0 (the capacity of the hand-over list): k_wf_trace marks the casts it hands over
+                               // WF_HIT_PENDING, k_wf_trace_wide stores THEIR hits by list position in a plane of their own,
+                               // and k_wf_shade's pass over the queue leaves them to a second launch over that list
 };
 
 // A path queue of capacity `cap` records is two planes of 32 bytes per record (the casts read the first only, the misses
@@ -616,6 +619,7 @@ PT_D bool unpack_hit(uint4 r, RawHit& h) {
 
 // The hit records of a chunk, two planes (k_wf_shade's pass over the queue reads the first only; a miss writes the first
 // only): hits[i] as a 4-byte word - primitive | flags, 0xffffffff = no hit - for i < cap, then (key, u, v, -) per entry.
+#define WF_HIT_PENDING 0xfffffffeu   // (bit 28 of a hit's word is always clear) the cast is still with k_wf_trace_wide
 PT_D uint32_t wf_hit_word(const uint4* hits, uint32_t i) { return ((const uint32_t*)hits)[i]; }
 PT_D void wf_store_hit(uint4* hits, uint32_t cap, uint32_t i, const RawHit& h, bool hit) {
     const uint4 r = pack_hit(h, hit);
@@ -940,6 +944,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                     const uint32_t slot = wf_reserve(&ctr[W.bounce].deferred_count, defer);
                     if (defer) {
                         deferred[slot] = idx;
+                        if (W.split_deferred) ((uint32_t*)hits)[idx] = WF_HIT_PENDING;
                         active = false;
                         lstate = WF_LANE_IDLE;
                     }
@@ -1006,6 +1011,8 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
                                                                             const uint32_t* __restrict__ deferred,
                                                                             const WfCounters* __restrict__ ctr,
                                                                             DevCounters* __restrict__ gctr) {
+    // (W.split_deferred: `hits` is the hand-over list's own plane, W.split_deferred records, indexed by list position -
+    // the pass of k_wf_shade over the queue, which runs meanwhile, must keep seeing WF_HIT_PENDING at the queue index)
     constexpr uint32_t L = WF_WIDE_LANES, GROUPS = WF_THREADS / L;
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
     __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
@@ -1163,11 +1170,12 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
         const bool found = best.pid != 0xffffffffu && best.key == kmin && best.ord == omin;
         const unsigned long long winners = __ballot(found) & group_mask;
         if (e < n) {
+            const uint32_t h_cap = W.split_deferred ? W.split_deferred : W.cap, h_idx = W.split_deferred ? e : idx;
             if (winners) {
                 if (lane == (uint32_t)__ffsll((long long)winners) - 1u)
-                    wf_store_hit(hits, W.cap, idx, best, hit_passes_slab(S, best.pid, T.o, T.d));
+                    wf_store_hit(hits, h_cap, h_idx, best, hit_passes_slab(S, best.pid, T.o, T.d));
             } else if (part == 0u) {
-                wf_store_hit(hits, W.cap, idx, best, false);
+                wf_store_hit(hits, h_cap, h_idx, best, false);
             }
         }
     }
@@ -1228,13 +1236,18 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
                                                   const uint32_t* __restrict__ draws,
                                                   float4* __restrict__ queue_out, float4* __restrict__ shadow_q,
                                                   float4* __restrict__ contrib, float* __restrict__ staging,
+                                                  const uint32_t* __restrict__ index_list,
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
+    // index_list (bounces >= 1): null - the whole queue, entries marked WF_HIT_PENDING left out; else the entries to shade:
+    // the hand-over list of k_wf_trace, whose casts k_wf_trace_wide has finished by now - `hits` is then that list's
+    // own plane (W.split_deferred records, by list position).  The pass over the queue runs WHILE k_wf_trace_wide walks
+    // those few long casts (16 lanes each, a launch bound by its longest cast).
     constexpr int GRID = GRIDX & 3;
     constexpr bool DIRL = GRIDX >= 4;
     static_assert(GRIDX != 4, "DIRL needs a grid mode");
     uint4* rng_planes_out = const_cast<uint4*>(rng_planes);   // GRID == 3 writes plane 1 (nobody reads it before bounce 1)
     static_assert(GRID < 2 || PRIMARY, "the camera grid serves bounce 0");
-    const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
+    const uint32_t n = PRIMARY ? W.n_items : index_list ? ctr[W.bounce].deferred_count : ctr[W.bounce].queue_count;
     uint32_t n_draws = 0, n_new = 0, n_moot = 0, n_hits = 0, n_cam_tris = 0;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};   // (GRID: casts made here)
     __shared__ uint32_t sh_cnt[2][WF_SHADE_THREADS / 64];
@@ -1246,7 +1259,9 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
     // the instruction count and the 52 active lanes per instruction unchanged, profiles/r02_experiments.txt item 13.)
     // One workgroup-wide step: thread t shades queue entry i (live = it has one).  Every thread of the workgroup
     // calls this together: the compaction at the end has barriers.
-    auto shade_one = [&](const uint32_t i, bool live) {
+    const uint32_t hit_cap = (!PRIMARY && index_list) ? W.split_deferred : W.cap;
+    auto shade_one = [&](const uint32_t e, bool live) {   // e: position in the queue / in index_list
+    const uint32_t i = (!PRIMARY && index_list && live) ? index_list[e] : e;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), color = mk3(0, 0, 0);
     uint32_t item = i, draw = 0, out_slot = 0;
     RawHit h;
@@ -1339,7 +1354,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
         item = __float_as_uint(q1.z);
         draw = ALPHA ? draws[i] : (__float_as_uint(q1.w) & 0xffffu);
         out_slot = __float_as_uint(q2.w);
-        hit = wf_load_hit(hits, W.cap, i, h);
+        hit = wf_load_hit(hits, hit_cap, e, h);
         if (out_slot == 0xffffffffu) live = false;  // (records of items outside the image; none since bounce 0 is fused)
     }
     const uint32_t bounce = PRIMARY ? 0u : W.bounce, bounces = W.P.bounces;   // (PRIMARY: no Russian roulette code at all)
@@ -1502,8 +1517,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
     };  // shade_one
     if (PRIMARY || !WF_SHADE_AGGREGATE) {
         // grid-stride over the queue, one workgroup-wide step at a time (the loop bound is uniform in the workgroup)
-        for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS)
-            shade_one(base + threadIdx.x, base + threadIdx.x < n);
+        for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS) {
+            const uint32_t e = base + threadIdx.x;
+            shade_one(e, e < n && (PRIMARY || wf_hit_word(hits, e) != WF_HIT_PENDING));
+        }
     } else {
         // Hit aggregation (bounces >= 1).  Three of four secondary rays of an open scene leave into the background:
         // shaded in queue order, 23 % of the lanes would carry the material fetch, the BRDF and the GGX sample while
@@ -1518,11 +1535,13 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
         uint32_t base = blockIdx.x * WF_SHADE_THREADS;
         while (true) {
             while (have < WF_SHADE_THREADS && base < n) {
-                const uint32_t i = base + threadIdx.x;
+                const uint32_t e = base + threadIdx.x;
+                const uint32_t i = (index_list && e < n) ? index_list[e] : e;   // (queue record; the hit is stored at e)
                 base += gridDim.x * WF_SHADE_THREADS;
                 bool is_hit = false;
-                if (i < n) {
-                    is_hit = wf_hit_word(hits, i) != 0xffffffffu;
+                const uint32_t word = e < n ? wf_hit_word(hits, e) : WF_HIT_PENDING;
+                if (word != WF_HIT_PENDING) {
+                    is_hit = word != 0xffffffffu;
                     if (!is_hit) {
                         const float4* qp = wf_path_rec(queue_in, W.cap, i);
                         const float4 q2 = qp[0], q3 = qp[1];
@@ -1544,7 +1563,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
                     if (k < wave) pos += agg_cnt[k];
                     total += agg_cnt[k];
                 }
-                if (is_hit) agg[pos] = i;
+                if (is_hit) agg[pos] = e;
                 have += total;
                 __syncthreads();
             }

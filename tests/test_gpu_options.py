@@ -38,6 +38,8 @@ SETTINGS = [
     {},                                   # default
     {"PT_WF_DEFER": "0"},                 # no hand-over to k_wf_trace_wide
     {"PT_WF_DEFER": "2"},                 # ... as early as possible (many casts through the wide kernel)
+    {"PT_WF_SPLIT": "0"},                 # k_wf_trace_wide on the main stream, one shade pass after it
+    {"PT_WF_SPLIT": "0", "PT_WF_DEFER": "2"},
     {"PT_WF_SORT": "1"},                  # octant bucketing of the survivors
     {"PT_WF_SORT": "2"},                  # hits shaded in material order
     {"PT_OG_FUSE_RNG": "0"},              # k_wf_rng stages the ChaCha words, bounce-0 kernel GRID 2
