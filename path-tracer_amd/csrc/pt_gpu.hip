@@ -1557,8 +1557,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       (!alpha || w.draws.try_ensure((size_t)cap * 4u)) &&   // RNG draw index of the alpha walk
                       (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u)) &&   // surfaces left to the KD-tree
                       // casts left to k_wf_trace_wide: at most one per lane in flight when the queue runs dry
-                      // (4 B the queue index + 20 B the hit k_wf_trace_wide finds, when the shade pass is split)
-                      (alpha || !wf_defer || w.deferred.try_ensure((size_t)s.trace_blocks * WF_THREADS * 24u));
+                      // (4 B the queue index + 20 B a hit + 4 B the progress of the walk: wf_list_* in pt_wavefront.h)
+                      (alpha || !wf_defer || w.deferred.try_ensure((size_t)s.trace_blocks * WF_THREADS * 28u));
             if (ok) {
                 if (multi_chunk) s.wf_cap_ok = cap;   // (a frame that fits in one chunk says nothing about larger ones)
                 break;
@@ -1769,7 +1769,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             const uint32_t list_cap = (uint32_t)s.trace_blocks * WF_THREADS;
                             uint4* list_hits = (uint4*)((uint32_t*)pipe.deferred.p + list_cap);
                             split_shade = wf_split && W.defer_age != 0u && pipe.side_wide != nullptr;
-                            W.split_deferred = split_shade ? list_cap : 0u;
+                            W.list_cap = list_cap;
+                            W.split_deferred = split_shade ? 1u : 0u;
                             PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
                                           (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (uint32_t*)pipe.deferred.p, wctr, gctr);
                             if (W.defer_age) {   // the casts the drained wavefronts handed over (pt_wavefront.h)
@@ -1820,7 +1821,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                         // ... and the casts that were with k_wf_trace_wide meanwhile: the hand-over list (at most one entry per
                         // lane of the trace grid; usually a few thousand - a launch that finds an empty list returns)
                         HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_wide, 0));
-                        shade_hits = (const uint4*)((const uint32_t*)pipe.deferred.p + W.split_deferred);
+                        shade_hits = (const uint4*)((const uint32_t*)pipe.deferred.p + W.list_cap);
                         shade_list = (const uint32_t*)pipe.deferred.p;
                         shade_grid = std::min(shade_grid, (uint32_t)s.n_cu);
                         launch_shade();
@@ -2382,7 +2383,7 @@ int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint
         int n_cu = 0;
         HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, scene->device));
         const uint32_t blocks = (uint32_t)std::max(1, n_cu) * 4u;
-        Staged<uint32_t> d_def(nullptr, (size_t)blocks * WF_THREADS);
+        Staged<uint32_t> d_def(nullptr, (size_t)blocks * WF_THREADS * 7);   // (index | carried hit | progress: wf_list_*)
         WfParams W{};
         W.n_items = (uint32_t)n;
         W.cap = cap;
@@ -2390,6 +2391,7 @@ int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint
         W.refill_min = 16;
         W.walk_steps = 12;
         W.defer_age = (mode & 2u) ? 1u : 0u;
+        W.list_cap = blocks * WF_THREADS;
         W.use_entry = mode & 1u;
         hipLaunchKernelGGL((k_wf_trace<false, false, false>), dim3(blocks), dim3(WF_THREADS), 0, 0, scene->dev, W, (const uint32_t*)nullptr,
                            d_q.d, d_hits.d, (const uint4*)nullptr, (uint32_t*)nullptr, d_def.d, d_ctr.d, (DevCounters*)nullptr);

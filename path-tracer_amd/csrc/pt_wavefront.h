@@ -75,9 +75,10 @@ struct WfParams {
     uint32_t sort_octants;  // k_wf_shade: bit 0 - survivors of a workgroup step bucketed by direction octant; bit 1 - hits shaded in material order
     uint32_t defer_age;     // k_wf_trace, queue exhausted: casts older than this many loop iterations go to k_wf_trace_wide (0: never)
     uint32_t use_entry;     // the queues carry entry words (trav_enter): casts of bounces >= 1 start at their primitive's home node
-    uint32_t split_deferred;   // != 0 (the capacity of the hand-over list): k_wf_trace marks the casts it hands over
-                               // WF_HIT_PENDING, k_wf_trace_wide stores THEIR hits by list position in a plane of their own,
-                               // and k_wf_shade's pass over the queue leaves them to a second launch over that list
+    uint32_t list_cap;         // capacity of the hand-over list (queue index | carried hit | progress, wf_list_*)
+    uint32_t split_deferred;   // k_wf_trace marks the casts it hands over WF_HIT_PENDING, k_wf_trace_wide stores THEIR hits by
+                               // list position in the list's own plane, and k_wf_shade's pass over the queue leaves them to a
+                               // second launch over that list
 };
 
 // A path queue of capacity `cap` records is two planes of 32 bytes per record (the casts read the first only, the misses
@@ -633,6 +634,29 @@ PT_D bool wf_load_hit(const uint4* hits, uint32_t cap, uint32_t i, RawHit& h) {
     return unpack_hit(make_uint4(x, k.x, k.y, k.z), h);
 }
 
+// The hand-over list (k_wf_trace -> k_wf_trace_wide), list_cap entries: the queue index (4 B), a hit plane like the
+// chunk's (20 B: the best hit of the leaves walked so far, later the cast's result if the shade pass is split) and the
+// distance up to which the tree has been walked (4 B).
+PT_D uint4* wf_list_hits(uint32_t* list, uint32_t list_cap) { return (uint4*)(list + list_cap); }
+PT_D const uint4* wf_list_hits(const uint32_t* list, uint32_t list_cap) { return (const uint4*)(list + list_cap); }
+PT_D float* wf_list_progress(uint32_t* list, uint32_t list_cap) { return (float*)(list + (size_t)list_cap * 6); }
+PT_D const float* wf_list_progress(const uint32_t* list, uint32_t list_cap) { return (const float*)(list + (size_t)list_cap * 6); }
+// (a carried hit keeps its PT_PRIM_EDGE mark - the hit word has no room for it - in the spare word of the second plane)
+PT_D void wf_store_carry(uint32_t* list, uint32_t list_cap, uint32_t slot, const RawHit& h) {
+    const bool hit = h.pid != 0xffffffffu;
+    const uint4 r = pack_hit(h, hit);
+    list[list_cap + slot] = r.x;
+    if (hit) ((uint4*)(list + (size_t)list_cap * 2))[slot] = make_uint4(r.y, r.z, r.w, h.pid & PT_PRIM_EDGE);
+}
+PT_D bool wf_load_carry(const uint32_t* list, uint32_t list_cap, uint32_t slot, RawHit& h) {
+    const uint32_t x = list[list_cap + slot];
+    if (x == 0xffffffffu) return false;
+    const uint4 k = ((const uint4*)(list + (size_t)list_cap * 2))[slot];
+    unpack_hit(make_uint4(x, k.x, k.y, k.z), h);
+    h.pid |= k.w & PT_PRIM_EDGE;
+    return true;
+}
+
 PT_D float wf_rng_float(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0f); }  // rng.gen::<f32>()
 
 // ---------------------------------------------------------------------------
@@ -943,7 +967,11 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                 if (wf_any(defer)) {
                     const uint32_t slot = wf_reserve(&ctr[W.bounce].deferred_count, defer);
                     if (defer) {
+                        // (the walk so far is not lost: the group starts at the current segment - everything nearer has
+                        // been visited, front to back - with the best hit of the leaves behind it)
                         deferred[slot] = idx;
+                        wf_store_carry(deferred, W.list_cap, slot, best);
+                        wf_list_progress(deferred, W.list_cap)[slot] = T.tmin;
                         if (W.split_deferred) ((uint32_t*)hits)[idx] = WF_HIT_PENDING;
                         active = false;
                         lstate = WF_LANE_IDLE;
@@ -1011,7 +1039,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
                                                                             const uint32_t* __restrict__ deferred,
                                                                             const WfCounters* __restrict__ ctr,
                                                                             DevCounters* __restrict__ gctr) {
-    // (W.split_deferred: `hits` is the hand-over list's own plane, W.split_deferred records, indexed by list position -
+    // (W.split_deferred: `hits` is the hand-over list's own plane, W.list_cap records, indexed by list position -
     // the pass of k_wf_shade over the queue, which runs meanwhile, must keep seeing WF_HIT_PENDING at the queue index)
     constexpr uint32_t L = WF_WIDE_LANES, GROUPS = WF_THREADS / L;
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
@@ -1045,7 +1073,14 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
         if (e < n) {
             const float4* q = wf_ray_rec(queue, idx);
             const float4 q0 = q[0], q1 = q[1];
-            in_scene = trav_start(S, T, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), 0.f);
+            // from where k_wf_trace left the walk (less the slack a restarted walk backs off by, kd_traverse)
+            const float walked = wf_list_progress(deferred, W.list_cap)[e];
+            const float t_start = walked > 0.f ? walked * (2.f - PT_EXIT_REL) - PT_EXIT_ABS : 0.f;
+            in_scene = trav_start(S, T, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), t_start > 0.f ? t_start : 0.f);
+            if (part == 0u) {   // ... with the best hit of the leaves behind that point
+                RawHit carried;
+                if (wf_load_carry(deferred, W.list_cap, e, carried)) best = carried;
+            }
         }
         bool busy = in_scene && part == 0u;   // the root segment; the other lanes live off what is handed over
         uint32_t dbg_rounds = 0, dbg_busy = 0;
@@ -1170,7 +1205,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
         const bool found = best.pid != 0xffffffffu && best.key == kmin && best.ord == omin;
         const unsigned long long winners = __ballot(found) & group_mask;
         if (e < n) {
-            const uint32_t h_cap = W.split_deferred ? W.split_deferred : W.cap, h_idx = W.split_deferred ? e : idx;
+            const uint32_t h_cap = W.split_deferred ? W.list_cap : W.cap, h_idx = W.split_deferred ? e : idx;
             if (winners) {
                 if (lane == (uint32_t)__ffsll((long long)winners) - 1u)
                     wf_store_hit(hits, h_cap, h_idx, best, hit_passes_slab(S, best.pid, T.o, T.d));
@@ -1240,7 +1275,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     // index_list (bounces >= 1): null - the whole queue, entries marked WF_HIT_PENDING left out; else the entries to shade:
     // the hand-over list of k_wf_trace, whose casts k_wf_trace_wide has finished by now - `hits` is then that list's
-    // own plane (W.split_deferred records, by list position).  The pass over the queue runs WHILE k_wf_trace_wide walks
+    // own plane (W.list_cap records, by list position).  The pass over the queue runs WHILE k_wf_trace_wide walks
     // those few long casts (16 lanes each, a launch bound by its longest cast).
     constexpr int GRID = GRIDX & 3;
     constexpr bool DIRL = GRIDX >= 4;
@@ -1259,7 +1294,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
     // the instruction count and the 52 active lanes per instruction unchanged, profiles/r02_experiments.txt item 13.)
     // One workgroup-wide step: thread t shades queue entry i (live = it has one).  Every thread of the workgroup
     // calls this together: the compaction at the end has barriers.
-    const uint32_t hit_cap = (!PRIMARY && index_list) ? W.split_deferred : W.cap;
+    const uint32_t hit_cap = (!PRIMARY && index_list) ? W.list_cap : W.cap;
     auto shade_one = [&](const uint32_t e, bool live) {   // e: position in the queue / in index_list
     const uint32_t i = (!PRIMARY && index_list && live) ? index_list[e] : e;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), color = mk3(0, 0, 0);
