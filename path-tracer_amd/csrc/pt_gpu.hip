@@ -1776,13 +1776,15 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             if (W.defer_age) {   // the casts the drained wavefronts handed over (pt_wavefront.h)
                                 // split shade pass: on a stream of its own, underneath k_wf_shade's pass over the queue
                                 hipStream_t st_wide = split_shade ? pipe.side_wide : st_main;
+                                // (16 Ki casts per pass; a workgroup without a cast returns at once)
+                                const uint32_t wide_grid = (uint32_t)s.n_cu * 4u * (WF_WIDE_LANES / 16u > 0u ? WF_WIDE_LANES / 16u : 1u);
                                 uint4* wide_hits = split_shade ? list_hits : (uint4*)pipe.hits.p;
                                 if (split_shade) {
                                     HIP_CHECK(hipEventRecord(pipe.ev_trace, st_main));
                                     HIP_CHECK(hipStreamWaitEvent(st_wide, pipe.ev_trace, 0));
                                 }
-                                if (counting) hipLaunchKernelGGL((k_wf_trace_wide<true>), dim3((uint32_t)s.n_cu * 4u), dim3(WF_THREADS), 0, st_wide, s.dev, W, (const float4*)q_in, wide_hits, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
-                                else hipLaunchKernelGGL((k_wf_trace_wide<false>), dim3((uint32_t)s.n_cu * 4u), dim3(WF_THREADS), 0, st_wide, s.dev, W, (const float4*)q_in, wide_hits, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
+                                if (counting) hipLaunchKernelGGL((k_wf_trace_wide<true>), dim3(wide_grid), dim3(WF_THREADS), 0, st_wide, s.dev, W, (const float4*)q_in, wide_hits, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
+                                else hipLaunchKernelGGL((k_wf_trace_wide<false>), dim3(wide_grid), dim3(WF_THREADS), 0, st_wide, s.dev, W, (const float4*)q_in, wide_hits, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
                                 HIP_CHECK(hipGetLastError());
                                 if (split_shade) HIP_CHECK(hipEventRecord(pipe.ev_wide, st_wide));
                             }
@@ -2397,7 +2399,7 @@ int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint
                            d_q.d, d_hits.d, (const uint4*)nullptr, (uint32_t*)nullptr, d_def.d, d_ctr.d, (DevCounters*)nullptr);
         HIP_CHECK(hipGetLastError());
         if (W.defer_age) {
-            hipLaunchKernelGGL((k_wf_trace_wide<false>), dim3((uint32_t)std::max(1, n_cu) * 4u), dim3(WF_THREADS), 0, 0, scene->dev, W,
+            hipLaunchKernelGGL((k_wf_trace_wide<false>), dim3((uint32_t)std::max(1, n_cu) * 4u * (WF_WIDE_LANES / 16u > 0u ? WF_WIDE_LANES / 16u : 1u)), dim3(WF_THREADS), 0, 0, scene->dev, W,
                                (const float4*)d_q.d, d_hits.d, (const uint32_t*)d_def.d, (const WfCounters*)d_ctr.d, (DevCounters*)nullptr);
             HIP_CHECK(hipGetLastError());
         }

@@ -1027,12 +1027,14 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
 // group's best distance with the traversal's usual slack; a handed-over segment starts no later than recorded).
 // ---------------------------------------------------------------------------
 #ifndef WF_WIDE_LANES
-#define WF_WIDE_LANES 16u
+// lanes per cast.  One shard of eight (MI355X, config 3), the k_wf_trace_wide launches of bounces 1 / 2 / 3:
+// 8: 480 / 335 / 95 us   16: 266 / 231 / 83 us   32: 207 / 200 / 69 us (profiles/r03_experiments.txt item 6)
+#define WF_WIDE_LANES 32u
 #endif
 #ifndef WF_WIDE_STEPS
 #define WF_WIDE_STEPS 2u
 #endif
-#define WF_WIDE_LIST 64u   // leaf records a group lists per round
+#define WF_WIDE_LIST (4u * WF_WIDE_LANES)   // leaf records a group lists per round
 template <bool COUNT>
 __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevScene S, WfParams W, const float4* __restrict__ queue,
                                                                             uint4* __restrict__ hits,
@@ -1054,7 +1056,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
     float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
     const TravStack st = {(wf_lds_u64*)(lds_stack + threadIdx.x), ov_node, ov_tmax, (const wf_lds_u64*)lds_top};
     const uint32_t group = threadIdx.x / L, part = threadIdx.x & (L - 1u), lane = threadIdx.x & 63u;
-    const unsigned long long group_mask = ((1ull << L) - 1ull) << (lane & ~(L - 1u));
+    const unsigned long long group_mask = L == 64u ? ~0ull : ((1ull << (L & 63u)) - 1ull) << (lane & ~(L - 1u));
     const unsigned long long below = (1ull << lane) - 1ull;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     // (whole wavefronts stay in the loops together: ballots and shuffles are wave-wide)
