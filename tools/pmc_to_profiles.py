@@ -52,7 +52,9 @@ for name, c in acc.items():
         "tcp_accesses_per_vmem_inst": round(c.get("TCP_TOTAL_ACCESSES_sum", 0) /
                                             max(1, c.get("SQ_INSTS_VMEM_RD", 0) + c.get("SQ_INSTS_VMEM_WR", 0)), 1),
     }
-json.dump({"workload": workload, "kernels": out}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+# the grid build of pt_scene_create (namespace ogb) runs once per scene in front of the timed region: its own section
+setup = {k: out.pop(k) for k in list(out) if k.startswith("ogb::")}
+json.dump({"workload": workload, "kernels": out, "setup_kernels": setup}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 dominant = max(out, key=lambda k: out[k]["kernel_ms_profiled"])
 t = out[dominant]
 json.dump({"workload": workload, "kernel": dominant, "hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
@@ -70,4 +72,6 @@ json.dump({"workload": workload, "kernel": dominant, "hbm_bytes_per_launch": rou
 for k, v in out.items():
     print(k, {a: v[a] for a in ("dispatches_per_frame", "hbm_bytes_per_frame", "active_lanes_per_valu_inst",
                                  "wait_pct_of_wave_cycles", "l1_hit_pct", "l2_hit_pct", "kernel_ms_profiled")})
+for k, v in setup.items():
+    print("(setup)", k, {a: v[a] for a in ("dispatches_per_frame", "hbm_bytes_per_frame", "kernel_ms_profiled")})
 print("total HBM bytes per frame: %.1f GB" % (sum(v["hbm_bytes_per_frame"] for v in out.values()) / 1e9))
