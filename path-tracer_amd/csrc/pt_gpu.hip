@@ -499,9 +499,15 @@ struct pt_scene {
     typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> TileKey;
     mutable std::map<TileKey, std::unique_ptr<DeviceBuffer>> tile_tables;
     mutable std::vector<hipEvent_t> events;
+    // One frame's launches as an instantiated hipGraph, per configuration (profile, options, output and queue addresses):
+    // the ~35 launches, memsets and cross-stream waits of a frame are captured once and replayed with ONE hipGraphLaunch
+    mutable std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;
+    mutable hipStream_t capture_stream = nullptr;
 
     ~pt_scene() {
         (void)hipSetDevice(device);
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+        if (capture_stream) (void)hipStreamDestroy(capture_stream);
         for (void* p : allocations) (void)hipFree(p);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         for (hipEvent_t e : {pipe.ev_shade, pipe.ev_shadow, pipe.ev_rng, pipe.ev_chunk, pipe.ev_trace, pipe.ev_wide})
@@ -1342,6 +1348,12 @@ hipEvent_t get_event(const pt_scene& s, size_t i) {
     return s.events[i];
 }
 
+#ifndef PT_GRAPH_DEFAULT
+// PT_GRAPH=1: frames replayed from a captured hipGraph (render_device).  Measured (MI355X, ROCm 7.2; config 3): a whole
+// frame 34.47 -> 34.40 ms, one shard of eight 5.49 -> 5.60 ms - the replay of the ~35 nodes on three streams is no faster
+// than their launches (the host is 30 frames ahead of the device either way; the 7 us between dependent kernels stay): off.
+#define PT_GRAPH_DEFAULT false
+#endif
 void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_in, void* d_rgb8, void* d_accum,
                    hipStream_t stream, bool allow_preview = false) {
     pt_opts o;
@@ -1605,6 +1617,45 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stage_stream));
     };
     DevCounters* gctr = (counting || exit_times) ? (DevCounters*)s.counter_buf.p : nullptr;
+    // ---- hipGraph: a plain frame (no timing events, counters, callbacks) is captured once per configuration - on a
+    // stream of the scene's own, the caller's may be the null stream - and replayed on the caller's stream afterwards.
+    // Everything the launches below depend on is in the key; the side streams join the capture through the events they
+    // wait for and are joined again before it ends.
+    static const bool wf_graph = [] {
+        const char* e = getenv("PT_GRAPH");
+        return e && *e ? atoi(e) != 0 : PT_GRAPH_DEFAULT;
+    }();
+    const hipStream_t user_stream = stream;
+    struct CaptureGuard {   // (an exception between begin and end must not leave the stream capturing)
+        hipStream_t st = nullptr;
+        ~CaptureGuard() {
+            if (!st) return;
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(st, &g);
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+        }
+    } capture;
+    std::vector<uint64_t> graph_key;
+    if (wf_graph && mode == 2 && !timing && !counting && !exit_times && !o.progress && !(allow_preview && o.preview)) {
+        const pt_scene::WfPipe& w = s.pipe;
+        graph_key = {p.width, p.height, p.samples, p.bounces, (uint64_t)p.tonemap, o.flags, o.shard_rank, o.shard_count, o.tile_w,
+                     o.tile_h, o.sample_batch, (uint64_t)d_rgb8, (uint64_t)accum, (uint64_t)d_tiles, cap, batch,
+                     (uint64_t)s.staging_buf.p, (uint64_t)w.queue[0].p, (uint64_t)w.queue[1].p, (uint64_t)w.hits.p,
+                     (uint64_t)w.shadow.p, (uint64_t)w.contrib.p, (uint64_t)w.ctr.p, (uint64_t)w.rng[0].p, (uint64_t)w.rng[1].p,
+                     (uint64_t)w.draws.p, (uint64_t)w.offgrid.p, (uint64_t)w.deferred.p, (uint64_t)s.trace_blocks,
+                     (uint64_t)s.shadow_blocks, (uint64_t)tm.n_local, (uint64_t)tm.n_local_tiles};
+        auto hit = s.graphs.find(graph_key);
+        if (hit != s.graphs.end()) {
+            HIP_CHECK(hipGraphLaunch(hit->second, user_stream));
+            return;
+        }
+        if (!s.capture_stream) HIP_CHECK(hipStreamCreateWithFlags(&s.capture_stream, hipStreamNonBlocking));
+        stream = s.capture_stream;
+        stage_stream = stream;
+        HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        capture.st = stream;
+    }
     for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
         P.sample_begin = s0;
         P.sample_end = std::min(p.samples, s0 + batch);
@@ -1920,6 +1971,22 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         HIP_CHECK(hipGetLastError());
     }
     if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
+    if (capture.st) {
+        hipGraph_t graph = nullptr;
+        capture.st = nullptr;
+        HIP_CHECK(hipStreamEndCapture(stream, &graph));
+        hipGraphExec_t exec = nullptr;
+        const hipError_t rc = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIP_CHECK(rc);
+        if (s.graphs.size() >= 16) {   // (configurations come and go with the caller's buffers: start over)
+            for (auto& g : s.graphs) (void)hipGraphExecDestroy(g.second);
+            s.graphs.clear();
+        }
+        s.graphs.emplace(std::move(graph_key), exec);
+        HIP_CHECK(hipGraphLaunch(exec, user_stream));
+        return;
+    }
 
     if (timing || counting || exit_times) HIP_CHECK(hipStreamSynchronize(stream));
     if (timing) {
