@@ -1490,6 +1490,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         const char* e = getenv("PT_WF_SPLIT");
         return e && *e ? atoi(e) != 0 : true;
     }();
+    static const bool wf_allwide = [] {   // experiment: every cast of the bounces >= 1 of an opaque scene through k_wf_trace_wide
+        const char* e = getenv("PT_WF_ALLWIDE");
+        return e && *e ? atoi(e) != 0 : false;
+    }();
     static const uint32_t wf_defer = [] {   // k_wf_trace: age (loop iterations) at which a cast leaves a drained wavefront
         const char* e = getenv("PT_WF_DEFER");
         return (uint32_t)(e && *e ? atoi(e) : 16);
@@ -1570,7 +1574,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u)) &&   // surfaces left to the KD-tree
                       // casts left to k_wf_trace_wide: at most one per lane in flight when the queue runs dry
                       // (4 B the queue index + 20 B a hit + 4 B the progress of the walk: wf_list_* in pt_wavefront.h)
-                      (alpha || !wf_defer || w.deferred.try_ensure((size_t)s.trace_blocks * WF_THREADS * 28u));
+                      (alpha || !wf_defer ||
+                       w.deferred.try_ensure((wf_allwide ? (size_t)cap : (size_t)s.trace_blocks * WF_THREADS) * 28u));
             if (ok) {
                 if (multi_chunk) s.wf_cap_ok = cap;   // (a frame that fits in one chunk says nothing about larger ones)
                 break;
@@ -1822,13 +1827,24 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             split_shade = wf_split && W.defer_age != 0u && pipe.side_wide != nullptr;
                             W.list_cap = list_cap;
                             W.split_deferred = split_shade ? 1u : 0u;
-                            PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
-                                          (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (uint32_t*)pipe.deferred.p, wctr, gctr);
+                            const bool allwide = wf_allwide && W.defer_age != 0u;
+                            if (allwide) {
+                                split_shade = false;
+                                W.list_cap = cap;
+                                W.split_deferred = 0u;
+                                hipLaunchKernelGGL(k_wf_list_identity, dim3((uint32_t)s.n_cu * 8u), dim3(256), 0, st_main,
+                                                   (uint32_t*)pipe.deferred.p, cap, wctr, b);
+                                HIP_CHECK(hipGetLastError());
+                            } else {
+                                PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
+                                              (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (uint32_t*)pipe.deferred.p, wctr, gctr);
+                            }
                             if (W.defer_age) {   // the casts the drained wavefronts handed over (pt_wavefront.h)
                                 // split shade pass: on a stream of its own, underneath k_wf_shade's pass over the queue
                                 hipStream_t st_wide = split_shade ? pipe.side_wide : st_main;
                                 // (16 Ki casts per pass; a workgroup without a cast returns at once)
-                                const uint32_t wide_grid = (uint32_t)s.n_cu * 4u * (WF_WIDE_LANES / 16u > 0u ? WF_WIDE_LANES / 16u : 1u);
+                                const uint32_t wide_grid = allwide ? (uint32_t)s.trace_blocks * 4u
+                                                                   : (uint32_t)s.n_cu * 4u * (WF_WIDE_LANES / 16u > 0u ? WF_WIDE_LANES / 16u : 1u);
                                 uint4* wide_hits = split_shade ? list_hits : (uint4*)pipe.hits.p;
                                 if (split_shade) {
                                     HIP_CHECK(hipEventRecord(pipe.ev_trace, st_main));

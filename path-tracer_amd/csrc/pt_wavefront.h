@@ -1034,6 +1034,19 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
 #ifndef WF_WIDE_STEPS
 #define WF_WIDE_STEPS 2u
 #endif
+// Experiment (PT_WF_ALLWIDE=1, profiles/r03_experiments.txt item 8): EVERY cast of a bounce >= 1 through the cooperative
+// kernel - the hand-over list becomes the identity over the queue, nothing carried.
+__global__ __launch_bounds__(256) void k_wf_list_identity(uint32_t* __restrict__ list, uint32_t list_cap, WfCounters* __restrict__ ctr,
+                                                          uint32_t bounce) {
+    const uint32_t n = ctr[bounce].queue_count;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+        list[e] = e;
+        list[list_cap + e] = 0xffffffffu;
+        wf_list_progress(list, list_cap)[e] = 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr[bounce].deferred_count = n;
+}
+
 #define WF_WIDE_LIST (4u * WF_WIDE_LANES)   // leaf records a group lists per round
 template <bool COUNT>
 __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevScene S, WfParams W, const float4* __restrict__ queue,

@@ -38,6 +38,7 @@ SETTINGS = [
     {},                                   # default
     {"PT_WF_DEFER": "0"},                 # no hand-over to k_wf_trace_wide
     {"PT_WF_DEFER": "2"},                 # ... as early as possible (many casts through the wide kernel)
+    {"PT_WF_ALLWIDE": "1"},               # every cast of the bounces >= 1 through the cooperative kernel (an experiment's path)
     {"PT_GRAPH": "1"},                    # the frame's launches captured once, replayed with one hipGraphLaunch per frame
     {"PT_WF_SPLIT": "0"},                 # k_wf_trace_wide on the main stream, one shade pass after it
     {"PT_WF_SPLIT": "0", "PT_WF_DEFER": "2"},
