@@ -1574,8 +1574,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u)) &&   // surfaces left to the KD-tree
                       // casts left to k_wf_trace_wide: at most one per lane in flight when the queue runs dry
                       // (4 B the queue index + 20 B a hit + 4 B the progress of the walk: wf_list_* in pt_wavefront.h)
-                      (alpha || !wf_defer ||
-                       w.deferred.try_ensure((wf_allwide ? (size_t)cap : (size_t)s.trace_blocks * WF_THREADS) * 28u));
+                      (!wf_defer ||
+                       w.deferred.try_ensure((wf_allwide && !alpha ? (size_t)cap : (size_t)s.trace_blocks * WF_THREADS) * 4u *
+                                             (alpha ? WF_LIST_WORDS_ALPHA : WF_LIST_WORDS_OPAQUE)));
             if (ok) {
                 if (multi_chunk) s.wf_cap_ok = cap;   // (a frame that fits in one chunk says nothing about larger ones)
                 break;
@@ -1820,14 +1821,14 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
 #undef PT_LAUNCH_OGP
                             HIP_CHECK(hipGetLastError());
                         } else {
-                            W.defer_age = (prim || alpha) ? 0u : wf_defer;
+                            W.defer_age = prim ? 0u : wf_defer;
                             // the hand-over list: queue indices, then (split shade pass) the plane of their hits
                             const uint32_t list_cap = (uint32_t)s.trace_blocks * WF_THREADS;
                             uint4* list_hits = (uint4*)((uint32_t*)pipe.deferred.p + list_cap);
                             split_shade = wf_split && W.defer_age != 0u && pipe.side_wide != nullptr;
                             W.list_cap = list_cap;
                             W.split_deferred = split_shade ? 1u : 0u;
-                            const bool allwide = wf_allwide && W.defer_age != 0u;
+                            const bool allwide = wf_allwide && !alpha && W.defer_age != 0u;
                             if (allwide) {
                                 split_shade = false;
                                 W.list_cap = cap;
@@ -1850,8 +1851,15 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                                     HIP_CHECK(hipEventRecord(pipe.ev_trace, st_main));
                                     HIP_CHECK(hipStreamWaitEvent(st_wide, pipe.ev_trace, 0));
                                 }
-                                if (counting) hipLaunchKernelGGL((k_wf_trace_wide<true>), dim3(wide_grid), dim3(WF_THREADS), 0, st_wide, s.dev, W, (const float4*)q_in, wide_hits, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
-                                else hipLaunchKernelGGL((k_wf_trace_wide<false>), dim3(wide_grid), dim3(WF_THREADS), 0, st_wide, s.dev, W, (const float4*)q_in, wide_hits, (const uint32_t*)pipe.deferred.p, (const WfCounters*)wctr, gctr);
+#define PT_LAUNCH_WIDE(C, A)                                                                                                  \
+    hipLaunchKernelGGL((k_wf_trace_wide<C, A>), dim3(wide_grid), dim3(WF_THREADS), 0, st_wide, s.dev, W, d_tiles, (const float4*)q_in, \
+                       wide_hits, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (const uint32_t*)pipe.deferred.p,             \
+                       (const WfCounters*)wctr, gctr)
+                                if (alpha && counting) PT_LAUNCH_WIDE(true, true);
+                                else if (alpha) PT_LAUNCH_WIDE(false, true);
+                                else if (counting) PT_LAUNCH_WIDE(true, false);
+                                else PT_LAUNCH_WIDE(false, false);
+#undef PT_LAUNCH_WIDE
                                 HIP_CHECK(hipGetLastError());
                                 if (split_shade) HIP_CHECK(hipEventRecord(pipe.ev_wide, st_wide));
                             }
@@ -2482,8 +2490,9 @@ int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint
                            d_q.d, d_hits.d, (const uint4*)nullptr, (uint32_t*)nullptr, d_def.d, d_ctr.d, (DevCounters*)nullptr);
         HIP_CHECK(hipGetLastError());
         if (W.defer_age) {
-            hipLaunchKernelGGL((k_wf_trace_wide<false>), dim3((uint32_t)std::max(1, n_cu) * 4u * (WF_WIDE_LANES / 16u > 0u ? WF_WIDE_LANES / 16u : 1u)), dim3(WF_THREADS), 0, 0, scene->dev, W,
-                               (const float4*)d_q.d, d_hits.d, (const uint32_t*)d_def.d, (const WfCounters*)d_ctr.d, (DevCounters*)nullptr);
+            hipLaunchKernelGGL((k_wf_trace_wide<false, false>), dim3((uint32_t)std::max(1, n_cu) * 4u * (WF_WIDE_LANES / 16u > 0u ? WF_WIDE_LANES / 16u : 1u)), dim3(WF_THREADS), 0, 0, scene->dev, W,
+                               (const uint32_t*)nullptr, (const float4*)d_q.d, d_hits.d, (const uint4*)nullptr, (uint32_t*)nullptr,
+                               (const uint32_t*)d_def.d, (const WfCounters*)d_ctr.d, (DevCounters*)nullptr);
             HIP_CHECK(hipGetLastError());
         }
         HIP_CHECK(hipDeviceSynchronize());

@@ -641,6 +641,31 @@ PT_D uint4* wf_list_hits(uint32_t* list, uint32_t list_cap) { return (uint4*)(li
 PT_D const uint4* wf_list_hits(const uint32_t* list, uint32_t list_cap) { return (const uint4*)(list + list_cap); }
 PT_D float* wf_list_progress(uint32_t* list, uint32_t list_cap) { return (float*)(list + (size_t)list_cap * 6); }
 PT_D const float* wf_list_progress(const uint32_t* list, uint32_t list_cap) { return (const float*)(list + (size_t)list_cap * 6); }
+// Translucent scenes (28 -> 60 B): the state of the alpha walk (mod.rs:188-205) - the last skipped hit as the lower bound of the
+// search (t_prev, ord_prev), the path's rng.gen() count, the last skipped surface ("kept", shaded if every hit is skipped).
+#define WF_LIST_WORDS_OPAQUE 7u
+#define WF_LIST_WORDS_ALPHA 15u
+PT_D void wf_store_alpha_state(uint32_t* list, uint32_t cap, uint32_t slot, float t_prev, uint32_t ord_prev, uint32_t draw,
+                               const RawHit& kept, bool have_kept) {
+    list[(size_t)cap * 7 + slot] = __float_as_uint(t_prev);
+    list[(size_t)cap * 8 + slot] = ord_prev;
+    list[(size_t)cap * 9 + slot] = draw;
+    const uint4 r = pack_hit(kept, have_kept);
+    list[(size_t)cap * 10 + slot] = r.x;
+    if (have_kept) ((uint4*)(list + (size_t)cap * 11))[slot] = make_uint4(r.y, r.z, r.w, kept.pid & PT_PRIM_EDGE);
+}
+PT_D bool wf_load_alpha_state(const uint32_t* list, uint32_t cap, uint32_t slot, float& t_prev, uint32_t& ord_prev, uint32_t& draw,
+                              RawHit& kept) {
+    t_prev = __uint_as_float(list[(size_t)cap * 7 + slot]);
+    ord_prev = list[(size_t)cap * 8 + slot];
+    draw = list[(size_t)cap * 9 + slot];
+    const uint32_t x = list[(size_t)cap * 10 + slot];
+    if (x == 0xffffffffu) return false;
+    const uint4 k = ((const uint4*)(list + (size_t)cap * 11))[slot];
+    unpack_hit(make_uint4(x, k.x, k.y, k.z), kept);
+    kept.pid |= k.w & PT_PRIM_EDGE;
+    return true;
+}
 // (a carried hit keeps its PT_PRIM_EDGE mark - the hit word has no room for it - in the spare word of the second plane)
 PT_D void wf_store_carry(uint32_t* list, uint32_t list_cap, uint32_t slot, const RawHit& h) {
     const bool hit = h.pid != 0xffffffffu;
@@ -960,7 +985,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
         // defer_age iterations is handed to k_wf_trace_wide (16 lanes per cast) instead of keeping the wavefront - and,
         // at the end, the whole launch - waiting for one lane: the last 1 % of the wavefronts of a launch used to leave
         // 0.2 ... 0.5 ms after the median one, a fifth of the launch for an eighth of a 1080p frame.
-        if (!ALPHA && !PRIMARY && W.defer_age != 0u) {
+        if (!PRIMARY && W.defer_age != 0u) {
             T.dneg += 8u;   // (bits 3 and up: the age of the cast in loop iterations; trav_start sets the register afresh)
             if (wf.done && wf.cur >= wf.end) {
                 const bool defer = active && T.dneg >= W.defer_age * 8u;
@@ -972,6 +997,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                         deferred[slot] = idx;
                         wf_store_carry(deferred, W.list_cap, slot, best);
                         wf_list_progress(deferred, W.list_cap)[slot] = T.tmin;
+                        if (ALPHA) wf_store_alpha_state(deferred, W.list_cap, slot, t_prev, ord_prev, draw, kept, have_kept);
                         if (W.split_deferred) ((uint32_t*)hits)[idx] = WF_HIT_PENDING;
                         active = false;
                         lstate = WF_LANE_IDLE;
@@ -1048,14 +1074,19 @@ __global__ __launch_bounds__(256) void k_wf_list_identity(uint32_t* __restrict__
 }
 
 #define WF_WIDE_LIST (4u * WF_WIDE_LANES)   // leaf records a group lists per round
-template <bool COUNT>
-__global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevScene S, WfParams W, const float4* __restrict__ queue,
+template <bool COUNT, bool ALPHA>
+__global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
+                                                                            const float4* __restrict__ queue,
                                                                             uint4* __restrict__ hits,
+                                                                            const uint4* __restrict__ rng_planes,
+                                                                            uint32_t* __restrict__ draws,
                                                                             const uint32_t* __restrict__ deferred,
                                                                             const WfCounters* __restrict__ ctr,
                                                                             DevCounters* __restrict__ gctr) {
     // (W.split_deferred: `hits` is the hand-over list's own plane, W.list_cap records, indexed by list position -
     // the pass of k_wf_shade over the queue, which runs meanwhile, must keep seeing WF_HIT_PENDING at the queue index)
+    // ALPHA: the group also finishes the alpha walk of its cast (mod.rs:188-205, as k_wf_trace's complete()): every lane
+    // holds the group's hit and evaluates opacity and draw alike, a skipped hit restarts the group behind it.
     constexpr uint32_t L = WF_WIDE_LANES, GROUPS = WF_THREADS / L;
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
     __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
@@ -1085,6 +1116,11 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
         best.flags = 0u;
         Trav T;
         bool in_scene = false;
+        // the alpha walk's state (group-uniform)
+        float t_prev = -INFINITY;
+        uint32_t ord_prev = 0u, draw = 0u, item = 0u;
+        RawHit kept = best;
+        bool have_kept = false;
         if (e < n) {
             const float4* q = wf_ray_rec(queue, idx);
             const float4 q0 = q[0], q1 = q[1];
@@ -1096,106 +1132,196 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
                 RawHit carried;
                 if (wf_load_carry(deferred, W.list_cap, e, carried)) best = carried;
             }
+            if (ALPHA) {
+                item = __float_as_uint(q1.z);
+                have_kept = wf_load_alpha_state(deferred, W.list_cap, e, t_prev, ord_prev, draw, kept);
+            }
         }
-        bool busy = in_scene && part == 0u;   // the root segment; the other lanes live off what is handed over
+        bool live = e < n;   // the group's cast is not answered yet
         uint32_t dbg_rounds = 0, dbg_busy = 0;
         const unsigned long long dbg_t0 = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        while (true) {
-            if (COUNT) dbg_rounds++;
-            // the group's best distance so far: what every lane culls against
-            float gkey = best.key;
+        bool again;
+        do {
+            again = false;
+            bool busy = in_scene && part == 0u;   // the root segment; the other lanes live off what is handed over
+            while (true) {
+                if (COUNT) dbg_rounds++;
+                // the group's best distance so far: what every lane culls against
+                float gkey = best.key;
 #pragma unroll
-            for (uint32_t m = L / 2u; m >= 1u; m >>= 1) {
-                const float k2 = __shfl_xor(gkey, (int)m);
-                gkey = k2 < gkey ? k2 : gkey;
-            }
-            // a lane without a segment goes on with its own stack (nothing left within gkey: the rest is dropped) ...
-            if (in_scene && !busy && T.sp > 0) {
-                busy = trav_pop(T, st, gkey);
-                if (!busy) T.sp = 0;
-            }
-            // ... or is handed the nearest pending segment of a lane that has one
-            const bool need = in_scene && !busy;
-            if (wf_any(need)) {
-                const bool can_give = busy && T.sp > 0;
-                const unsigned long long m_need = __ballot(need) & group_mask, m_give = __ballot(can_give) & group_mask;
-                const uint32_t n_need = (uint32_t)__popcll(m_need), n_can = (uint32_t)__popcll(m_give);
-                const uint32_t n_give = n_need < n_can ? n_need : n_can;
-                if (can_give && (uint32_t)__popcll(m_give & below) < n_give) {
-                    const uint32_t slot = (uint32_t)__popcll(m_give & below);
-                    uint32_t node;
-                    float tmax;
-                    --T.sp;
-                    stack_get(st, T.sp, node, tmax);
-                    pool_node[group][slot] = node;
-                    pool_tmin[group][slot] = T.tmax;   // (its true start if nothing nearer was handed over before: never later)
-                    pool_tmax[group][slot] = tmax;
+                for (uint32_t m = L / 2u; m >= 1u; m >>= 1) {
+                    const float k2 = __shfl_xor(gkey, (int)m);
+                    gkey = k2 < gkey ? k2 : gkey;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (need && (uint32_t)__popcll(m_need & below) < n_give) {
-                    const uint32_t slot = (uint32_t)__popcll(m_need & below);
-                    T.node = pool_node[group][slot];
-                    T.tmin = pool_tmin[group][slot];
-                    T.tmax = pool_tmax[group][slot];
-                    T.sp = 0;
-                    busy = !(T.tmin * trav_key_scale(T) > gkey * PT_EXIT_REL + PT_EXIT_ABS);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (!wf_any(busy)) break;   // (a lane without a segment has an empty stack: the casts of this wavefront are done)
-            // up to WF_WIDE_STEPS nodes
-            bool at_leaf = false;
-            for (uint32_t k = 0; k < WF_WIDE_STEPS; ++k) {
-                if (busy && !at_leaf) {
-                    if (COUNT) dbg_busy++;
-                    const uint32_t state = trav_step<COUNT>(S, T, st, gkey, lc);
-                    at_leaf = state == WF_LANE_LEAF;
-                    busy = state != WF_LANE_DONE;
+                // a lane without a segment goes on with its own stack (nothing left within gkey: the rest is dropped) ...
+                if (in_scene && !busy && T.sp > 0) {
+                    busy = trav_pop(T, st, gkey);
                     if (!busy) T.sp = 0;
                 }
-            }
-            // the leaves reached: tested by the group together - the records of ALL of them are listed in LDS and lane p
-            // takes entries p, p + L, ... of the list, so one round costs one trip to memory for its leaves
-            if (wf_any(at_leaf)) {
-                const uint32_t my_count = at_leaf ? T.leaf.y >> 2 : 0u;
-                uint32_t incl = my_count;
+                // ... or is handed the nearest pending segment of a lane that has one
+                const bool need = in_scene && !busy;
+                if (wf_any(need)) {
+                    const bool can_give = busy && T.sp > 0;
+                    const unsigned long long m_need = __ballot(need) & group_mask, m_give = __ballot(can_give) & group_mask;
+                    const uint32_t n_need = (uint32_t)__popcll(m_need), n_can = (uint32_t)__popcll(m_give);
+                    const uint32_t n_give = n_need < n_can ? n_need : n_can;
+                    if (can_give && (uint32_t)__popcll(m_give & below) < n_give) {
+                        const uint32_t slot = (uint32_t)__popcll(m_give & below);
+                        uint32_t node;
+                        float tmax;
+                        --T.sp;
+                        stack_get(st, T.sp, node, tmax);
+                        pool_node[group][slot] = node;
+                        pool_tmin[group][slot] = T.tmax;   // (its true start if nothing nearer was handed over before: never later)
+                        pool_tmax[group][slot] = tmax;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (need && (uint32_t)__popcll(m_need & below) < n_give) {
+                        const uint32_t slot = (uint32_t)__popcll(m_need & below);
+                        T.node = pool_node[group][slot];
+                        T.tmin = pool_tmin[group][slot];
+                        T.tmax = pool_tmax[group][slot];
+                        T.sp = 0;
+                        busy = !(T.tmin * trav_key_scale(T) > gkey * PT_EXIT_REL + PT_EXIT_ABS);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (!wf_any(busy)) break;   // (a lane without a segment has an empty stack: the casts of this wavefront are done)
+                // up to WF_WIDE_STEPS nodes
+                bool at_leaf = false;
+                for (uint32_t k = 0; k < WF_WIDE_STEPS; ++k) {
+                    if (busy && !at_leaf) {
+                        if (COUNT) dbg_busy++;
+                        const uint32_t state = trav_step<COUNT>(S, T, st, gkey, lc);
+                        at_leaf = state == WF_LANE_LEAF;
+                        busy = state != WF_LANE_DONE;
+                        if (!busy) T.sp = 0;
+                    }
+                }
+                // the leaves reached: tested by the group together - the records of ALL of them are listed in LDS and lane p
+                // takes entries p, p + L, ... of the list, so one round costs one trip to memory for its leaves
+                if (wf_any(at_leaf)) {
+                    const uint32_t my_count = at_leaf ? T.leaf.y >> 2 : 0u;
+                    uint32_t incl = my_count;
 #pragma unroll
-                for (uint32_t m = 1u; m < L; m <<= 1) {
-                    const uint32_t up = __shfl_up(incl, (int)m);
-                    if (part >= m) incl += up;
-                }
-                const uint32_t total = __shfl(incl, (int)((lane & ~(L - 1u)) + L - 1u));
-                if (at_leaf) {
-                    const uint32_t off = incl - my_count;
-                    for (uint32_t j = 0; j < my_count; ++j)
-                        if (off + j < WF_WIDE_LIST) leaf_list[group][off + j] = T.leaf.x + j;
-                    busy = false;   // (its next segment: from the stack, in the next round)
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t listed = total < WF_WIDE_LIST ? total : WF_WIDE_LIST;
-                for (uint32_t i = part; i < listed; i += L) {
-                    const float4* rec = S.leaf_prims + (size_t)leaf_list[group][i] * 3;
-                    float4 q0, q1, q2;
-                    load_prim_record(rec, q0, q1, q2);
-                    og_test_closest<COUNT>(T.o, T.d, q0, q1, q2, -INFINITY, 0u, best, lc);
-                }
-                if (__builtin_expect(wf_any(total > WF_WIDE_LIST), 0)) {   // (more records than the list holds: the owners test the rest)
+                    for (uint32_t m = 1u; m < L; m <<= 1) {
+                        const uint32_t up = __shfl_up(incl, (int)m);
+                        if (part >= m) incl += up;
+                    }
+                    const uint32_t total = __shfl(incl, (int)((lane & ~(L - 1u)) + L - 1u));
                     if (at_leaf) {
                         const uint32_t off = incl - my_count;
                         for (uint32_t j = 0; j < my_count; ++j)
-                            if (off + j >= WF_WIDE_LIST) {
-                                const float4* rec = S.leaf_prims + (size_t)(T.leaf.x + j) * 3;
-                                float4 q0, q1, q2;
-                    load_prim_record(rec, q0, q1, q2);
-                    og_test_closest<COUNT>(T.o, T.d, q0, q1, q2, -INFINITY, 0u, best, lc);
-                            }
+                            if (off + j < WF_WIDE_LIST) leaf_list[group][off + j] = T.leaf.x + j;
+                        busy = false;   // (its next segment: from the stack, in the next round)
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t listed = total < WF_WIDE_LIST ? total : WF_WIDE_LIST;
+                    for (uint32_t i = part; i < listed; i += L) {
+                        const float4* rec = S.leaf_prims + (size_t)leaf_list[group][i] * 3;
+                        float4 q0, q1, q2;
+                        load_prim_record(rec, q0, q1, q2);
+                        og_test_closest<COUNT>(T.o, T.d, q0, q1, q2, t_prev, ord_prev, best, lc);
+                    }
+                    if (__builtin_expect(wf_any(total > WF_WIDE_LIST), 0)) {   // (more records than the list holds: the owners test the rest)
+                        if (at_leaf) {
+                            const uint32_t off = incl - my_count;
+                            for (uint32_t j = 0; j < my_count; ++j)
+                                if (off + j >= WF_WIDE_LIST) {
+                                    const float4* rec = S.leaf_prims + (size_t)(T.leaf.x + j) * 3;
+                                    float4 q0, q1, q2;
+                        load_prim_record(rec, q0, q1, q2);
+                        og_test_closest<COUNT>(T.o, T.d, q0, q1, q2, t_prev, ord_prev, best, lc);
+                                }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            // the group's minimum of (key, ord)
+            float kmin = best.key;
+            uint32_t omin = best.ord;
+#pragma unroll
+            for (uint32_t m = L / 2u; m >= 1u; m >>= 1) {
+                const float k2 = __shfl_xor(kmin, (int)m);
+                const uint32_t o2 = __shfl_xor(omin, (int)m);
+                if (key_less(k2, o2, kmin, omin)) {
+                    kmin = k2;
+                    omin = o2;
+                }
+            }
+            const bool found = best.pid != 0xffffffffu && best.key == kmin && best.ord == omin;
+            const unsigned long long winners = __ballot(found) & group_mask;
+            const uint32_t h_cap = W.split_deferred ? W.list_cap : W.cap, h_idx = W.split_deferred ? e : idx;
+            if (!ALPHA) {
+                if (live) {
+                    if (winners) {
+                        if (lane == (uint32_t)__ffsll((long long)winners) - 1u)
+                            wf_store_hit(hits, h_cap, h_idx, best, hit_passes_slab(S, best.pid, T.o, T.d));
+                    } else if (part == 0u) {
+                        wf_store_hit(hits, h_cap, h_idx, best, false);
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+            } else {
+                // every lane of the group takes the winner's record
+                const int src = winners ? __ffsll((long long)winners) - 1 : (int)lane;
+                RawHit win;
+                win.key = __shfl(best.key, src);
+                win.ord = __shfl(best.ord, src);
+                win.pid = __shfl(best.pid, src);
+                win.u = __shfl(best.u, src);
+                win.v = __shfl(best.v, src);
+                win.flags = __shfl(best.flags, src);
+                if (live) {
+                    bool hit = winners != 0ull;
+                    if (hit && !hit_passes_slab(S, win.pid, T.o, T.d)) {   // kdtree-ray's box test: no hits at all
+                        hit = false;
+                        have_kept = false;
+                    }
+                    bool finished = true;
+                    if (hit) {
+                        const float opacity = hit_opacity(S, T.o, T.d, win);
+                        if (COUNT && part == 0u) lc.shaded++;
+                        bool stop = opacity >= 1.f;
+                        if (!stop && opacity > 0.001f) {
+                            WfRng fb;
+                            fb.block = 0xffffffffu;
+                            stop = wf_rng_draw(fb, W, tile_offsets, rng_planes, item, draw++) < opacity;
+                            if (COUNT && part == 0u) lc.shadow_rays++;   // (the alpha-draw counter, as in k_wf_trace)
+                        }
+                        if (!stop) {   // skipped: remember it, the group looks for the next entry behind it
+                            kept = win;
+                            have_kept = true;
+                            t_prev = win.key;
+                            ord_prev = win.ord;
+                            best.key = INFINITY;
+                            best.ord = 0xffffffffu;
+                            best.pid = 0xffffffffu;
+                            in_scene = trav_start(S, T, T.o, T.d, next_start(t_prev, T.d));
+                            if (COUNT && part == 0u) lc.restarts++;
+                            finished = !in_scene;
+                            if (finished) hit = false;
+                        }
+                    }
+                    if (finished) {
+                        if (!hit && have_kept) {   // every hit skipped: the last one is shaded
+                            win = kept;
+                            hit = true;
+                        }
+                        if (part == 0u) {
+                            wf_store_hit(hits, h_cap, h_idx, win, hit);
+                            draws[idx] = draw;
+                        }
+                        live = false;
+                        in_scene = false;
+                    } else {
+                        again = true;
+                    }
+                }
             }
-        }
+        } while (ALPHA && wf_any(again));
 #ifndef WF_STAMPS   // (a -DWF_STAMPS build keeps its phase cycles in the same slots)
         if (COUNT && e < n) {   // diagnostics (PT_DEBUG_HIST): rounds per cast, node steps
             if (part == 0u) atomicAdd(&gctr->stamps[0], (unsigned long long)dbg_rounds);
@@ -1205,35 +1331,17 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
             if (part == 0u) atomicAdd(&gctr->stamps[5], __builtin_amdgcn_s_memrealtime() - dbg_t0);
         }
 #endif
-        // the group's minimum of (key, ord)
-        float kmin = best.key;
-        uint32_t omin = best.ord;
-#pragma unroll
-        for (uint32_t m = L / 2u; m >= 1u; m >>= 1) {
-            const float k2 = __shfl_xor(kmin, (int)m);
-            const uint32_t o2 = __shfl_xor(omin, (int)m);
-            if (key_less(k2, o2, kmin, omin)) {
-                kmin = k2;
-                omin = o2;
-            }
-        }
-        const bool found = best.pid != 0xffffffffu && best.key == kmin && best.ord == omin;
-        const unsigned long long winners = __ballot(found) & group_mask;
-        if (e < n) {
-            const uint32_t h_cap = W.split_deferred ? W.list_cap : W.cap, h_idx = W.split_deferred ? e : idx;
-            if (winners) {
-                if (lane == (uint32_t)__ffsll((long long)winners) - 1u)
-                    wf_store_hit(hits, h_cap, h_idx, best, hit_passes_slab(S, best.pid, T.o, T.d));
-            } else if (part == 0u) {
-                wf_store_hit(hits, h_cap, h_idx, best, false);
-            }
-        }
     }
     if (COUNT) {
         atomicAdd(&gctr->nodes_visited, (unsigned long long)lc.nodes);
         atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
         atomicAdd(&gctr->trace_nodes, (unsigned long long)lc.nodes);
         atomicAdd(&gctr->trace_tris, (unsigned long long)lc.tris);
+        if (ALPHA) {
+            atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
+            atomicAdd(&gctr->shaded_hits, (unsigned long long)lc.shaded);
+            atomicAdd(&gctr->rng_draws, (unsigned long long)lc.shadow_rays);
+        }
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&gctr->deferred_casts, (unsigned long long)n);
     }
 }
