@@ -487,7 +487,7 @@ struct pt_scene {
     // The queues of the chunk of work items in flight.  The shadow casts of bounce b run on a side stream
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
-        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid, deferred;
+        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid, deferred, block_mask;
         hipStream_t side = nullptr, side_rng = nullptr, side_wide = nullptr;
         hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr, ev_trace = nullptr, ev_wide = nullptr;
     };
@@ -1574,6 +1574,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u)) &&   // surfaces left to the KD-tree
                       // casts left to k_wf_trace_wide: at most one per lane in flight when the queue runs dry
                       // (4 B the queue index + 20 B a hit + 4 B the progress of the walk: wf_list_* in pt_wavefront.h)
+                      (!(use_cam_grid && use_light_grids) || w.block_mask.try_ensure((size_t)blocks64 * 4u + 4u)) &&
                       (!wf_defer ||
                        w.deferred.try_ensure((wf_allwide && !alpha ? (size_t)cap : (size_t)s.trace_blocks * WF_THREADS) * 4u *
                                              (alpha ? WF_LIST_WORDS_ALPHA : WF_LIST_WORDS_OPAQUE)));
@@ -1581,7 +1582,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 if (multi_chunk) s.wf_cap_ok = cap;   // (a frame that fits in one chunk says nothing about larger ones)
                 break;
             }
-            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1], &w.draws, &w.offgrid, &w.deferred})
+            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1], &w.draws, &w.offgrid, &w.deferred, &w.block_mask})
                 b->release();
             if (cap <= (1u << 20))
                 fail(PT_ERR_DEVICE, "out of device memory: the path queues need %zu bytes for %u work items",
@@ -1650,7 +1651,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                      (uint64_t)s.staging_buf.p, (uint64_t)w.queue[0].p, (uint64_t)w.queue[1].p, (uint64_t)w.hits.p,
                      (uint64_t)w.shadow.p, (uint64_t)w.contrib.p, (uint64_t)w.ctr.p, (uint64_t)w.rng[0].p, (uint64_t)w.rng[1].p,
                      (uint64_t)w.draws.p, (uint64_t)w.offgrid.p, (uint64_t)w.deferred.p, (uint64_t)s.trace_blocks,
-                     (uint64_t)s.shadow_blocks, (uint64_t)tm.n_local, (uint64_t)tm.n_local_tiles};
+                     (uint64_t)s.shadow_blocks, (uint64_t)tm.n_local, (uint64_t)tm.n_local_tiles, (uint64_t)w.block_mask.p};
         auto hit = s.graphs.find(graph_key);
         if (hit != s.graphs.end()) {
             HIP_CHECK(hipGraphLaunch(hit->second, user_stream));
@@ -1661,6 +1662,24 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         stage_stream = stream;
         HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         capture.st = stream;
+    }
+    // bounce 0 through the camera grid: the 8x8 pixel blocks no camera ray can hit anything in (k_cam_block_mask) are
+    // found once per frame; their wavefronts write the background without a ChaCha block or a cast.  PT_CAM_CULL=0: off
+    static const bool cam_cull = [] {
+        const char* e = getenv("PT_CAM_CULL");
+        return e && *e ? atoi(e) != 0 : true;
+    }();
+    const uint32_t* block_empty = nullptr;
+    if (cam_cull && mode == 2 && use_cam_grid && use_light_grids && !counting) {
+        RenderParams P1 = P;
+        P1.sample_begin = 0;
+        P1.sample_end = 1;
+        pt_fastdiv_make(1u, P1.div_batch);
+        HIP_CHECK(hipMemsetAsync((uint32_t*)s.pipe.block_mask.p + blocks64, 0, 4, stream));
+        hipLaunchKernelGGL(k_cam_block_mask, dim3((blocks64 * 64u + 255u) / 256u), dim3(256), 0, stream, s.dev, P1, d_tiles, blocks64,
+                           (uint32_t*)s.pipe.block_mask.p);
+        HIP_CHECK(hipGetLastError());
+        block_empty = (const uint32_t*)s.pipe.block_mask.p;
     }
     for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
         P.sample_begin = s0;
@@ -1698,6 +1717,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 W.item_base = base;
                 W.n_items = std::min(cap, total_items - base);
                 W.cap = cap;
+                W.n_mask_blocks = blocks64;
                 uint4* rng_planes = (uint4*)pipe.rng[rng_ahead ? (chunk_no & 1u) : 0u].p;
                 // coherence sorting of the survivors by direction octant: measured (MI355X, config 3) trace of bounce 1
                 // 9.50 -> 9.25 ms, but the bounce-0 kernel 19.0 -> 20.2 ms: off by default
@@ -1785,7 +1805,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
 // k_wf_shade<ALPHA, COUNT, PRIMARY, GRID>
 #define PT_SHADE_ARGS                                                                                                         \
     s.dev, W, d_tiles, (const float4*)q_in, shade_hits, (const uint4*)rng_planes, (const uint32_t*)pipe.draws.p, \
-        q_out, (float4*)pipe.shadow.p, (float4*)pipe.contrib.p, (float*)s.staging_buf.p, shade_list, wctr, gctr
+        q_out, (float4*)pipe.shadow.p, (float4*)pipe.contrib.p, (float*)s.staging_buf.p, shade_list,                 \
+        (grid_mode >= 2 ? block_empty : (const uint32_t*)nullptr), wctr, gctr
 #define PT_LAUNCH_SHADE(A, C, P, G)                                                                                    \
     hipLaunchKernelGGL((k_wf_shade<A, C, P, G>), dim3(shade_grid), dim3(WF_SHADE_THREADS), 0, st_main, PT_SHADE_ARGS)
 #define PT_LAUNCH_SHADE_G(G)                                                   \

@@ -29,6 +29,7 @@
 // Work item -> pixel / sample (see the item numbering in pt_gpu.hip).
 struct ItemRef {
     uint32_t x, y, global_index, out_index, sample;  // sample is 1-based (mod.rs:105)
+    uint32_t block;                                  // the 8x8 pixel block (a wavefront's 64 items), numbered over the rank's tiles
     bool valid;
 };
 
@@ -55,6 +56,7 @@ __device__ __forceinline__ ItemRef decode_item(const RenderParams& P, const uint
     r.valid = tile_y < P.tiles_y && r.x < P.width && r.y < P.height;
     r.global_index = r.x + r.y * P.width;
     r.sample = P.sample_begin + 1u + s_rel;
+    r.block = b64;
     if (P.shard_count <= 1) {
         r.out_index = r.global_index;
     } else {
@@ -75,6 +77,7 @@ struct WfParams {
     uint32_t sort_octants;  // k_wf_shade: bit 0 - survivors of a workgroup step bucketed by direction octant; bit 1 - hits shaded in material order
     uint32_t defer_age;     // k_wf_trace, queue exhausted: casts older than this many loop iterations go to k_wf_trace_wide (0: never)
     uint32_t use_entry;     // the queues carry entry words (trav_enter): casts of bounces >= 1 start at their primitive's home node
+    uint32_t n_mask_blocks;    // k_cam_block_mask's table: one word per 8x8 pixel block of the rank, then the number of empty ones
     uint32_t list_cap;         // capacity of the hand-over list (queue index | carried hit | progress, wf_list_*)
     uint32_t split_deferred;   // k_wf_trace marks the casts it hands over WF_HIT_PENDING, k_wf_trace_wide stores THEIR hits by
                                // list position in the list's own plane, and k_wf_shade's pass over the queue leaves them to a
@@ -683,6 +686,63 @@ PT_D bool wf_load_carry(const uint32_t* list, uint32_t list_cap, uint32_t slot, 
 }
 
 PT_D float wf_rng_float(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0f); }  // rng.gen::<f32>()
+
+// ---------------------------------------------------------------------------
+// Camera-grid cull (bounce 0, fused kernel): which 8x8 pixel blocks can no camera ray hit anything in?  One thread per
+// pixel, every frame (a few ten microseconds).  A pixel's jittered rays (mod.rs:110-120: x + r1, y + r2 with r in [0, 1))
+// are positive combinations of its four corner rays (r = 0 and r = 1.0f: primary_screen is monotone in r), so on ONE face
+// of the cube map - a convex cone - they stay on that face and their cell coordinates, a projective image of the pixel
+// rectangle, stay inside the bounding box of the corners' cells.  If every cell of that box, one more ring of cells for
+// the rounding of og_cell, has an empty list (and the grid lists no primitive globally) the lists - conservative by
+// construction (host/og_raster.h) - prove that every such ray misses: the sample's colour is the background whatever
+// its random numbers are, and its StdRng feeds nothing else (one generator per sample).  Boxes that touch a face's
+// edge, corners on different faces: not empty.  A block is empty if its 64 pixels are (pixels outside the image count).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cam_block_mask(DevScene S, RenderParams P, const uint32_t* __restrict__ tile_offsets,
+                                                        uint32_t n_blocks, uint32_t* __restrict__ block_empty) {
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;   // block * 64 + pixel of the block (a batch of ONE sample)
+    const bool in_range = (item >> 6) < n_blocks;
+    bool empty = true;
+    if (in_range) {
+        const ItemRef it = decode_item(P, tile_offsets, item);
+        if (it.valid) {
+            const DevGrid& G = S.cam_grid;
+            empty = G.n_global == 0u;
+            uint32_t face0 = 0, cu0 = 0xffffffffu, cu1 = 0, cv0 = 0xffffffffu, cv1 = 0;
+            for (uint32_t c = 0; c < 4u && empty; ++c) {
+                float sx, sy;
+                f3 o, d;
+                primary_screen(S, it.x, it.y, P.width, P.height, (c & 1u) ? 1.0f : 0.0f, (c & 2u) ? 1.0f : 0.0f, sx, sy);
+                primary_from_screen(S, sx, sy, o, d);
+                if (!(d.x == d.x && d.y == d.y && d.z == d.z)) empty = false;
+                const uint32_t cell = og_cell(G, d);
+                const uint32_t face = cell / (G.res * G.res), rest = cell - face * G.res * G.res;
+                const uint32_t cv = rest / G.res, cu = rest - cv * G.res;
+                if (c == 0u) face0 = face;
+                else if (face != face0) empty = false;
+                cu0 = cu < cu0 ? cu : cu0;
+                cu1 = cu > cu1 ? cu : cu1;
+                cv0 = cv < cv0 ? cv : cv0;
+                cv1 = cv > cv1 ? cv : cv1;
+            }
+            // one ring of cells more; a box at the face's edge could have neighbours on another face
+            if (empty && (cu0 == 0u || cv0 == 0u || cu1 + 1u >= G.res || cv1 + 1u >= G.res)) empty = false;
+            if (empty && (cu1 - cu0 > 16u || cv1 - cv0 > 16u)) empty = false;   // (a grid much finer than the pixels: not worth the loop)
+            if (empty) {
+                for (uint32_t cv = cv0 - 1u; cv <= cv1 + 1u && empty; ++cv) {
+                    const uint32_t row = (face0 * G.res + cv) * G.res;
+                    // (the offsets are cumulative: a run of cells is empty iff its ends' offsets agree)
+                    if (G.cell_off[row + cu1 + 2u] != G.cell_off[row + cu0 - 1u]) empty = false;
+                }
+            }
+        }
+    }
+    const bool all_empty = __all(empty);
+    if ((threadIdx.x & 63u) == 0u && in_range) {
+        block_empty[item >> 6] = all_empty ? 1u : 0u;
+        if (all_empty) atomicAdd(&block_empty[n_blocks], 1u);   // (word n_blocks, zeroed by the host: how many are empty)
+    }
+}
 
 // ---------------------------------------------------------------------------
 // rng: ChaCha12 block 0 of every item of the chunk, once, with every lane busy.  The block costs ~700
@@ -1395,6 +1455,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
                                                   float4* __restrict__ queue_out, float4* __restrict__ shadow_q,
                                                   float4* __restrict__ contrib, float* __restrict__ staging,
                                                   const uint32_t* __restrict__ index_list,
+                                                  const uint32_t* __restrict__ block_empty,
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     // index_list (bounces >= 1): null - the whole queue, entries marked WF_HIT_PENDING left out; else the entries to shade:
     // the hand-over list of k_wf_trace, whose casts k_wf_trace_wide has finished by now - `hits` is then that list's
@@ -1675,9 +1736,42 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
     };  // shade_one
     if (PRIMARY || !WF_SHADE_AGGREGATE) {
         // grid-stride over the queue, one workgroup-wide step at a time (the loop bound is uniform in the workgroup)
+        // Camera-grid cull (k_cam_block_mask): no camera ray of an EMPTY 8x8 pixel block can hit anything, so its samples
+        // are the background - no ChaCha block, no cast (the instrumented variant counts them the long way).  A wavefront
+        // is one block of one sample; chunks and queues are whole wavefronts.  The background is written by a loop of its
+        // own in front of the shading loop (its address arithmetic stays out of that loop's registers).
+        // (word W.n_mask_blocks of the table: the number of empty blocks - a frame without one pays nothing here)
+        const bool cull = PRIMARY && GRID >= 2 && !COUNT && block_empty != nullptr && block_empty[W.n_mask_blocks] != 0u;
+        if (cull) {
+            for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS) {
+                const uint32_t e = base + threadIdx.x;
+                if (e < n && block_empty[pt_fastdiv((W.item_base + e) >> 6, W.P.div_batch)] != 0u) {
+                    const ItemRef it = decode_item(W.P, tile_offsets, W.item_base + e);
+                    if (it.valid) {   // background (mod.rs:184-186) with the initial throughput and colour
+                        const f3 c = mk3(0.f, 0.f, 0.f) + mul_ew(mk3(1.f, 1.f, 1.f), ld3(S.background));
+                        float* out = staging + (size_t)((it.sample - 1u - W.P.sample_begin) * W.P.n_local + it.out_index) * 3;
+                        out[0] = c.x;
+                        out[1] = c.y;
+                        out[2] = c.z;
+                    }
+                }
+            }
+        }
         for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS) {
             const uint32_t e = base + threadIdx.x;
-            shade_one(e, e < n && (PRIMARY || wf_hit_word(hits, e) != WF_HIT_PENDING));
+            bool live = e < n && (PRIMARY || wf_hit_word(hits, e) != WF_HIT_PENDING);
+            if (cull) {   // a step whose four wavefronts are all empty skips the compaction's barriers as well
+                const uint32_t g0 = (W.item_base + base) >> 6;
+                bool step_empty = true;
+#pragma unroll
+                for (uint32_t k = 0; k < WF_SHADE_THREADS / 64; ++k) {
+                    const bool em = base + 64u * k >= n || block_empty[pt_fastdiv(g0 + k, W.P.div_batch)] != 0u;
+                    step_empty = step_empty && em;
+                    live = (k == wave && em) ? false : live;
+                }
+                if (step_empty) continue;   // (the same answer in every thread of the workgroup)
+            }
+            shade_one(e, live);
         }
     } else {
         // Hit aggregation (bounces >= 1).  Three of four secondary rays of an open scene leave into the background:

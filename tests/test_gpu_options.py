@@ -38,6 +38,7 @@ SETTINGS = [
     {},                                   # default
     {"PT_WF_DEFER": "0"},                 # no hand-over to k_wf_trace_wide
     {"PT_WF_DEFER": "2"},                 # ... as early as possible (many casts through the wide kernel)
+    {"PT_CAM_CULL": "0"},                 # no camera-grid cull: every sample of an empty 8x8 block computes its ChaCha block and casts
     {"PT_WF_ALLWIDE": "1"},               # every cast of the bounces >= 1 through the cooperative kernel (an experiment's path)
     {"PT_GRAPH": "1"},                    # the frame's launches captured once, replayed with one hipGraphLaunch per frame
     {"PT_WF_SPLIT": "0"},                 # k_wf_trace_wide on the main stream, one shade pass after it
@@ -65,7 +66,7 @@ EXPECT_GRIDS = {"0.02": "512 0", "0.001": "0 0"}
 def run_child(extra):
     env = dict(os.environ)
     for k in list(env):
-        if k.startswith(("PT_WF_", "PT_OG", "PT_SHADE_", "PT_TILE_", "PT_KD_", "PT_GRAPH")):
+        if k.startswith(("PT_WF_", "PT_OG", "PT_SHADE_", "PT_TILE_", "PT_KD_", "PT_GRAPH", "PT_CAM_")):
             del env[k]
     env.update(extra)
     code = CHILD % {"root": str(ROOT), "scene": str(ROOT / "tests/golden/scenes/alpha_transparency/scene.isf")}
