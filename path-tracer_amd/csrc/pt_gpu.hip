@@ -160,14 +160,22 @@ __global__ __launch_bounds__(256) void k_render(DevScene S, RenderParams P, cons
 // accum[p] (+)= staging[0][p] + staging[1][p] + ... in sample order: the reference's
 // `*pixel += color` once per sample pass (mod.rs:105,130).
 __global__ __launch_bounds__(256) void k_accumulate(const float* __restrict__ staging, float* __restrict__ accum,
-                                                    uint32_t n_local, uint32_t batch, int first) {
+                                                    uint32_t n_local, uint32_t batch, int first,
+                                                    const uint8_t* __restrict__ pixel_empty, float bg_r, float bg_g, float bg_b) {
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n_local) return;
     f3 acc = mk3(0.f, 0.f, 0.f);
     if (!first) acc = mk3(accum[3 * (size_t)p], accum[3 * (size_t)p + 1], accum[3 * (size_t)p + 2]);
-    for (uint32_t s = 0; s < batch; ++s) {
-        const float* v = staging + ((size_t)s * n_local + p) * 3;
-        acc = acc + mk3(v[0], v[1], v[2]);
+    if (pixel_empty != nullptr && pixel_empty[p]) {
+        // camera-grid cull (k_cam_block_mask): every sample of this pixel is the background - the value the bounce-0
+        // kernel would have staged (mod.rs:184-186 with the initial throughput and colour), added once per sample
+        const f3 c = mk3(0.f, 0.f, 0.f) + mul_ew(mk3(1.f, 1.f, 1.f), mk3(bg_r, bg_g, bg_b));
+        for (uint32_t s = 0; s < batch; ++s) acc = acc + c;
+    } else {
+        for (uint32_t s = 0; s < batch; ++s) {
+            const float* v = staging + ((size_t)s * n_local + p) * 3;
+            acc = acc + mk3(v[0], v[1], v[2]);
+        }
     }
     accum[3 * (size_t)p] = acc.x;
     accum[3 * (size_t)p + 1] = acc.y;
@@ -1574,7 +1582,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u)) &&   // surfaces left to the KD-tree
                       // casts left to k_wf_trace_wide: at most one per lane in flight when the queue runs dry
                       // (4 B the queue index + 20 B a hit + 4 B the progress of the walk: wf_list_* in pt_wavefront.h)
-                      (!(use_cam_grid && use_light_grids) || w.block_mask.try_ensure((size_t)blocks64 * 4u + 4u)) &&
+                      (!(use_cam_grid && use_light_grids) || w.block_mask.try_ensure((size_t)blocks64 * 4u + 4u + tm.n_local)) &&
                       (!wf_defer ||
                        w.deferred.try_ensure((wf_allwide && !alpha ? (size_t)cap : (size_t)s.trace_blocks * WF_THREADS) * 4u *
                                              (alpha ? WF_LIST_WORDS_ALPHA : WF_LIST_WORDS_OPAQUE)));
@@ -1677,7 +1685,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         pt_fastdiv_make(1u, P1.div_batch);
         HIP_CHECK(hipMemsetAsync((uint32_t*)s.pipe.block_mask.p + blocks64, 0, 4, stream));
         hipLaunchKernelGGL(k_cam_block_mask, dim3((blocks64 * 64u + 255u) / 256u), dim3(256), 0, stream, s.dev, P1, d_tiles, blocks64,
-                           (uint32_t*)s.pipe.block_mask.p);
+                           (uint32_t*)s.pipe.block_mask.p, (uint8_t*)((uint32_t*)s.pipe.block_mask.p + blocks64 + 1u));
         HIP_CHECK(hipGetLastError());
         block_empty = (const uint32_t*)s.pipe.block_mask.p;
     }
@@ -1989,7 +1997,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         if (mode >= 1) {
             stage_begin(4);
             hipLaunchKernelGGL(k_accumulate, dim3(((uint32_t)tm.n_local + 255u) / 256u), dim3(256), 0, stream,
-                               (const float*)s.staging_buf.p, accum, (uint32_t)tm.n_local, nb, s0 == 0 ? 1 : 0);
+                               (const float*)s.staging_buf.p, accum, (uint32_t)tm.n_local, nb, s0 == 0 ? 1 : 0,
+                               block_empty ? (const uint8_t*)(block_empty + blocks64 + 1u) : (const uint8_t*)nullptr,
+                               s.dev.background[0], s.dev.background[1], s.dev.background[2]);
             HIP_CHECK(hipGetLastError());
             stage_end();
         }

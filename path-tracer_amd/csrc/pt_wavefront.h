@@ -699,13 +699,16 @@ PT_D float wf_rng_float(uint32_t word) { return (float)(word >> 8) * (1.0f / 167
 // edge, corners on different faces: not empty.  A block is empty if its 64 pixels are (pixels outside the image count).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cam_block_mask(DevScene S, RenderParams P, const uint32_t* __restrict__ tile_offsets,
-                                                        uint32_t n_blocks, uint32_t* __restrict__ block_empty) {
+                                                        uint32_t n_blocks, uint32_t* __restrict__ block_empty,
+                                                        uint8_t* __restrict__ pixel_empty) {
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;   // block * 64 + pixel of the block (a batch of ONE sample)
     const bool in_range = (item >> 6) < n_blocks;
     bool empty = true;
+    uint32_t out_index = 0xffffffffu;
     if (in_range) {
         const ItemRef it = decode_item(P, tile_offsets, item);
         if (it.valid) {
+            out_index = it.out_index;
             const DevGrid& G = S.cam_grid;
             empty = G.n_global == 0u;
             uint32_t face0 = 0, cu0 = 0xffffffffu, cu1 = 0, cv0 = 0xffffffffu, cv1 = 0;
@@ -738,6 +741,8 @@ __global__ __launch_bounds__(256) void k_cam_block_mask(DevScene S, RenderParams
         }
     }
     const bool all_empty = __all(empty);
+    // (per pixel for k_accumulate, which adds the background itself: an empty block's samples are never staged)
+    if (out_index != 0xffffffffu) pixel_empty[out_index] = all_empty ? 1 : 0;
     if ((threadIdx.x & 63u) == 0u && in_range) {
         block_empty[item >> 6] = all_empty ? 1u : 0u;
         if (all_empty) atomicAdd(&block_empty[n_blocks], 1u);   // (word n_blocks, zeroed by the host: how many are empty)
@@ -1738,25 +1743,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_
         // grid-stride over the queue, one workgroup-wide step at a time (the loop bound is uniform in the workgroup)
         // Camera-grid cull (k_cam_block_mask): no camera ray of an EMPTY 8x8 pixel block can hit anything, so its samples
         // are the background - no ChaCha block, no cast (the instrumented variant counts them the long way).  A wavefront
-        // is one block of one sample; chunks and queues are whole wavefronts.  The background is written by a loop of its
-        // own in front of the shading loop (its address arithmetic stays out of that loop's registers).
+        // is one block of one sample; chunks and queues are whole wavefronts.  Nothing is staged for them: k_accumulate
+        // adds the background for the pixels of an empty block itself, once per sample.
         // (word W.n_mask_blocks of the table: the number of empty blocks - a frame without one pays nothing here)
         const bool cull = PRIMARY && GRID >= 2 && !COUNT && block_empty != nullptr && block_empty[W.n_mask_blocks] != 0u;
-        if (cull) {
-            for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS) {
-                const uint32_t e = base + threadIdx.x;
-                if (e < n && block_empty[pt_fastdiv((W.item_base + e) >> 6, W.P.div_batch)] != 0u) {
-                    const ItemRef it = decode_item(W.P, tile_offsets, W.item_base + e);
-                    if (it.valid) {   // background (mod.rs:184-186) with the initial throughput and colour
-                        const f3 c = mk3(0.f, 0.f, 0.f) + mul_ew(mk3(1.f, 1.f, 1.f), ld3(S.background));
-                        float* out = staging + (size_t)((it.sample - 1u - W.P.sample_begin) * W.P.n_local + it.out_index) * 3;
-                        out[0] = c.x;
-                        out[1] = c.y;
-                        out[2] = c.z;
-                    }
-                }
-            }
-        }
         for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS) {
             const uint32_t e = base + threadIdx.x;
             bool live = e < n && (PRIMARY || wf_hit_word(hits, e) != WF_HIT_PENDING);
