@@ -243,6 +243,8 @@ def main():
     # ray, 8 B per KD node visited, 36 B per primitive tested, 160 B per shaded hit (96 B vertex attributes + 64 B
     # material record) - whatever the implementation keeps in registers or caches instead of moving it.
     roofline = None
+    # the camera-grid cull of the timed frames (rank 0's tiles): blocks whose samples are the background without RNG or cast
+    cull_blocks, cull_empty = gscene.cull_stats()
     counters = None
     if not args.no_counters:
         copts = pta.Opts.make(flags=pta.PT_FLAG_COUNTERS | args.opt_flags, device=local_rank, shard_rank=rank,
@@ -442,7 +444,12 @@ def main():
                        "kd": {k: info[k] for k in ("n_prims", "n_kd_nodes", "n_kd_leaves", "n_leaf_refs", "kd_depth", "n_edge_prims")},
                        "origin_grids": {k: info[k] for k in ("cam_grid_res", "light_grids", "grid_refs")},
                        "setup_seconds": round(setup_s, 2), "kd_build_seconds": round(info["kd_build_seconds"], 2),
-                       "grid_build_seconds": round(info["grid_build_seconds"], 2)},
+                       "grid_build_seconds": round(info["grid_build_seconds"], 2),
+                       "bounce0_cull": {"pixel_blocks_8x8": cull_blocks, "empty": cull_empty,
+                                        "frac": round(cull_empty / cull_blocks, 4) if cull_blocks else None,
+                                        "note": "blocks of rank 0 no camera ray can hit anything in (all cells of the camera grid under "
+                                                "their pixels are empty): their samples are the background, without ChaCha block "
+                                                "or cast; PT_CAM_CULL=0 renders them the long way, same bits"}},
             "roofline": roofline,
             "bound_measured": roofline["bound_measured"] if roofline else None,
             "moved_bytes_frac": roofline["moved_bytes_frac"] if roofline else None,

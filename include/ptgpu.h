@@ -310,6 +310,11 @@ typedef struct pt_counters {
 
 int pt_get_timing(const pt_scene* scene, pt_timing* out);
 int pt_get_counters(const pt_scene* scene, pt_counters* out);
+/* The camera-grid cull of the last frame rendered with this scene (synchronises the device): the number of 8x8 pixel
+ * blocks of the rank's tiles and how many of them no camera ray can hit anything in - their samples are the background
+ * (Renderer::render's miss branch, renderer/mod.rs:184-186) without an RNG block or a cast.  0 blocks: no cull ran
+ * (no camera grid, PT_FLAG_NO_GRIDS / PT_FLAG_MEGAKERNEL / PT_FLAG_COUNTERS, PT_CAM_CULL=0). */
+int pt_get_cull_stats(const pt_scene* scene, uint32_t* n_blocks, uint32_t* n_empty);
 
 /* Scene statistics after the KD build. */
 typedef struct pt_scene_info {

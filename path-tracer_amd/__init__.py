@@ -175,7 +175,7 @@ HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_s
 GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_prep_create", "pt_prep_destroy", "pt_scene_create_from_prep",
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_gather_tiles", "pt_render_gathered", "pt_local_pixel_count", "pt_local_pixel_map",
                "pt_render", "pt_render_device", "pt_debug_render", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
-               "pt_scene_get_info", "pt_scene_grid_header", "pt_scene_grid_copy", "pt_trace_rays", "pt_trace_rays_wavefront",
+               "pt_scene_get_info", "pt_get_cull_stats", "pt_scene_grid_header", "pt_scene_grid_copy", "pt_trace_rays", "pt_trace_rays_wavefront",
                "pt_trace_rays_all", "pt_intersect_triangles",
                "pt_rng_words", "pt_eval_math", "pt_measure_copy_bandwidth", "pt_measure_gather_rate", "pt_last_error",
                "pt_version"]
@@ -259,6 +259,7 @@ def gpu_lib():
         L.pt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp]
         L.pt_trace_rays_wavefront.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, vp]
         L.pt_scene_grid_header.argtypes = [vp, C.c_uint32, vp]
+        L.pt_get_cull_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.pt_scene_grid_copy.argtypes = [vp, C.c_uint32, vp, vp]
         L.pt_trace_rays_all.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
         L.pt_intersect_triangles.argtypes = [C.c_int, vp, vp, C.c_uint64, vp]
@@ -534,6 +535,12 @@ class GpuScene:
         t = Timing()
         check_gpu(self.lib.pt_get_timing(self.handle, C.byref(t)))
         return t
+
+    def cull_stats(self):
+        """(8x8 pixel blocks, blocks the camera-grid cull found empty) of the last frame; (0, 0): no cull ran."""
+        n, e = C.c_uint32(), C.c_uint32()
+        check_gpu(self.lib.pt_get_cull_stats(self.handle, C.byref(n), C.byref(e)))
+        return n.value, e.value
 
     def counters(self):
         c = Counters()

@@ -501,6 +501,7 @@ struct pt_scene {
     };
     mutable WfPipe pipe;
     mutable int trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
+    mutable uint32_t last_mask_blocks = 0;   // blocks of the last frame's camera-grid cull table (0: no cull in that frame)
     mutable uint32_t wf_cap_ok = 0;   // largest queue capacity the device provided so far (0: not tried)
     // tile tables of the sharded renders, one per configuration (image size, rank, count, tile size) and never rewritten:
     // pt_render_device is asynchronous, two calls for different ranks may be in flight on the caller's streams at once
@@ -1689,6 +1690,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         HIP_CHECK(hipGetLastError());
         block_empty = (const uint32_t*)s.pipe.block_mask.p;
     }
+    s.last_mask_blocks = block_empty ? blocks64 : 0u;
     for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
         P.sample_begin = s0;
         P.sample_end = std::min(p.samples, s0 + batch);
@@ -2450,6 +2452,18 @@ int pt_get_counters(const pt_scene* scene, pt_counters* out) {
     if (!scene || !out) return PT_ERR_INVALID;
     *out = scene->counters;
     return PT_OK;
+}
+int pt_get_cull_stats(const pt_scene* scene, uint32_t* n_blocks, uint32_t* n_empty) {
+    return guarded([&] {
+        if (!scene || !n_blocks || !n_empty) fail(PT_ERR_INVALID, "pt_get_cull_stats: null argument");
+        *n_blocks = scene->last_mask_blocks;
+        *n_empty = 0;
+        if (scene->last_mask_blocks) {
+            HIP_CHECK(hipSetDevice(scene->device));
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipMemcpy(n_empty, (const uint32_t*)scene->pipe.block_mask.p + scene->last_mask_blocks, 4, hipMemcpyDeviceToHost));
+        }
+    });
 }
 int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out) {
     if (!scene || !out) return PT_ERR_INVALID;

@@ -14,7 +14,7 @@
 #include "pt_integrator.h"
 
 // Cell of direction w (host mirror: path-tracer_amd/__init__.py OriginGrid.cells, tests/test_origin_grid.py).
-PT_D uint32_t og_cell(const DevGrid& G, f3 w) {
+PT_D void og_cell_coords(const DevGrid& G, f3 w, uint32_t& face, uint32_t& cu_out, uint32_t& cv_out) {
     const float ax = fabsf(w.x), ay = fabsf(w.y), az = fabsf(w.z);
     const bool fx = ax >= ay && ax >= az, fy = !fx && ay >= az;
     const float wa = fx ? w.x : (fy ? w.y : w.z);
@@ -25,8 +25,14 @@ PT_D uint32_t og_cell(const DevGrid& G, f3 w) {
     const float top = (float)(G.res - 1u);
     const float cu = fu >= 0.f ? fminf(floorf(fu), top) : 0.f;   // (NaN -> cell 0: such a ray hits nothing anyway)
     const float cv = fv >= 0.f ? fminf(floorf(fv), top) : 0.f;
-    const uint32_t face = (fx ? 0u : (fy ? 2u : 4u)) + (wa < 0.f ? 1u : 0u);
-    return (face * G.res + (uint32_t)cv) * G.res + (uint32_t)cu;
+    face = (fx ? 0u : (fy ? 2u : 4u)) + (wa < 0.f ? 1u : 0u);
+    cu_out = (uint32_t)cu;
+    cv_out = (uint32_t)cv;
+}
+PT_D uint32_t og_cell(const DevGrid& G, f3 w) {
+    uint32_t face, cu, cv;
+    og_cell_coords(G, w, face, cu, cv);
+    return (face * G.res + cv) * G.res + cu;
 }
 
 // Orthographic grid: cell of the ray ORIGIN p (host mirror: OriginGrid.cells), and the scan limit -depth(p).

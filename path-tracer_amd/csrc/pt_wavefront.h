@@ -718,9 +718,8 @@ __global__ __launch_bounds__(256) void k_cam_block_mask(DevScene S, RenderParams
                 primary_screen(S, it.x, it.y, P.width, P.height, (c & 1u) ? 1.0f : 0.0f, (c & 2u) ? 1.0f : 0.0f, sx, sy);
                 primary_from_screen(S, sx, sy, o, d);
                 if (!(d.x == d.x && d.y == d.y && d.z == d.z)) empty = false;
-                const uint32_t cell = og_cell(G, d);
-                const uint32_t face = cell / (G.res * G.res), rest = cell - face * G.res * G.res;
-                const uint32_t cv = rest / G.res, cu = rest - cv * G.res;
+                uint32_t face, cu, cv;
+                og_cell_coords(G, d, face, cu, cv);   // (og_cell's own arithmetic)
                 if (c == 0u) face0 = face;
                 else if (face != face0) empty = false;
                 cu0 = cu < cu0 ? cu : cu0;
