@@ -415,6 +415,32 @@ def test_grid_kd_and_megakernel_paths_agree(pta, scene_cache, gpu_scene_cache, n
         assert c1[k] == c2[k], (k, c1[k], c2[k])
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_camera_grid_cull_is_exact(pta, gpu_scene_cache, name):
+    """The bounce-0 cull (k_cam_block_mask: 8x8 pixel blocks under which every cell of the camera grid is empty are the
+    background without an RNG block or a cast) at odd image sizes and aspect ratios - block and pixel edges in new places
+    relative to the silhouettes: the frame equals the KD-tree path's, which knows no grid and no cull, bit for bit; shards
+    (their own block numbering) and sample batches included.  Every reference scene has background pixels: the cull bites."""
+    g = gpu_scene_cache(name)
+    for (w, h) in ((333, 187), (97, 61), (640, 200), (64, 360)):
+        prof = pta.Profile.make(w, h, 3, 2)
+        rgb, acc = g.render(prof)
+        blocks, empty = g.cull_stats()
+        assert blocks > 0 and empty < blocks and (empty > 0 or (w, h) != (333, 187)), (name, w, h, blocks, empty)
+        rgb_kd, acc_kd = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_NO_GRIDS))
+        assert g.cull_stats() == (0, 0)
+        assert np.array_equal(bits(acc), bits(acc_kd)) and np.array_equal(rgb, rgb_kd), (name, w, h)
+    prof = pta.Profile.make(333, 187, 5, 2)
+    full_rgb, full_acc = g.render(prof)
+    batched_rgb, batched_acc = g.render(prof, pta.Opts.make(sample_batch=2))
+    assert np.array_equal(bits(full_acc), bits(batched_acc)) and np.array_equal(full_rgb, batched_rgb)
+    for rank in (0, 2):
+        opts = pta.Opts.make(shard_rank=rank, shard_count=3, tile_w=32, tile_h=32)
+        rgb, acc = g.render(prof, opts)
+        px = pta.local_pixel_map(prof, opts)
+        assert np.array_equal(bits(acc), bits(full_acc[px])) and np.array_equal(rgb, full_rgb[px]), (name, rank)
+
+
 def test_generated_scene_grid_and_kd_paths_agree(pta):
     for flags in (0, 1):   # opaque, translucent shells
         scene = pta.HostScene.generate_ps5(30000, seed=0, flags=flags)
