@@ -37,6 +37,7 @@ def lib():
         L.pto_rng_words.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
         L.pto_eval_math.argtypes = [C.c_int, vp, C.c_uint64, vp]
         L.pto_primary_ray.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp]
+        L.pto_path_rays.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, vp]
         L.pto_max_threads.restype = C.c_int
         L.pto_last_error.restype = C.c_char_p
         _lib = L
@@ -97,6 +98,13 @@ class OracleScene:
         out = np.zeros(6, np.float32)
         _check(lib().pto_primary_ray(self.handle, C.byref(profile), pixel, sample, out.ctypes.data))
         return out
+
+    def path_rays(self, profile, pixel, sample, max_rays=4096):
+        """Study hook: every ray ray_cast sees while one sample is rendered (camera ray, shadow rays, bounce rays)."""
+        out = np.zeros((max_rays, 6), np.float32)
+        n = C.c_uint32(0)
+        _check(lib().pto_path_rays(self.handle, C.byref(profile), pixel, sample, out.ctypes.data, max_rays, C.byref(n)))
+        return out[: min(n.value, max_rays)].copy()
 
     def close(self):
         if self.handle:

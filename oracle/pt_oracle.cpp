@@ -487,7 +487,14 @@ void test_prim(const pto_scene& s, uint32_t prim, const Ray& ray, std::vector<Hi
 }
 
 // ray_cast — renderer/utils.rs:11-21: every hit of every model, stable-sorted by distance.
+// Study hook (pto_path_rays): the rays ray_cast is called with while one sample is rendered, six floats each.
+static thread_local std::vector<float>* g_ray_log = nullptr;
+
 void ray_cast(const pto_scene& s, const Ray& ray, CastScratch& sc, uint64_t* numeric_errors) {
+    if (g_ray_log) {
+        const float r6[6] = {ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x, ray.direction.y, ray.direction.z};
+        g_ray_log->insert(g_ray_log->end(), r6, r6 + 6);
+    }
     sc.hits.clear();
     if (!(s.mode & PTO_NO_SCENE_SLAB) && !kdtree_ray_slab(s.scene_box, ray)) return;  // no space passes: no candidates
     if (!(s.mode & PTO_BVH)) {
@@ -1025,6 +1032,26 @@ int pto_render_partial(const pto_scene* s, const pt_profile* profile, uint32_t s
         }
     }
     if (stats) *stats = total;
+    return PT_OK;
+}
+
+// Study hook: every ray ray_cast sees while sample `sample` (1-based) of pixel `pixel` is rendered - the camera ray, the
+// shadow rays of every shaded surface, the bounce rays - in call order.  Returns the number of rays (at most max_rays kept).
+int pto_path_rays(const pto_scene* s, const pt_profile* profile, uint64_t pixel, uint32_t sample, float* out6, uint32_t max_rays,
+                  uint32_t* n_rays) {
+    if (!s || !profile || !out6 || !n_rays) return set_err(PT_ERR_INVALID, "pto_path_rays: null argument");
+    const pt_profile p = *profile;
+    if (pixel >= (uint64_t)p.width * p.height || sample == 0 || sample > p.samples)
+        return set_err(PT_ERR_INVALID, "pto_path_rays: pixel / sample out of range");
+    std::vector<float> log;
+    Ctx c(*s, p);
+    StdRng rng((uint64_t)sample + pixel * (uint64_t)p.samples);
+    Ray ray = primary_ray(*s, p, pixel, rng);
+    g_ray_log = &log;
+    (void)render_pixel(c, ray, rng);
+    g_ray_log = nullptr;
+    *n_rays = (uint32_t)(log.size() / 6);
+    memcpy(out6, log.data(), sizeof(float) * 6 * std::min<size_t>(max_rays, *n_rays));
     return PT_OK;
 }
 

@@ -92,6 +92,9 @@ int pto_eval_math(int fn, const float* x, uint64_t n, float* out);
  * (renderer/mod.rs:107-124): out = origin3, direction3. */
 int pto_primary_ray(const pto_scene* s, const pt_profile* profile, uint64_t pixel, uint32_t sample,
                     float* out6);
+/* Study hook: the rays ray_cast is called with while sample `sample` (1-based) of `pixel` is rendered, in call order. */
+int pto_path_rays(const pto_scene* s, const pt_profile* profile, uint64_t pixel, uint32_t sample, float* out6, uint32_t max_rays,
+                  uint32_t* n_rays);
 
 /* OpenMP threads pto_render uses for threads <= 0. */
 int pto_max_threads(void);

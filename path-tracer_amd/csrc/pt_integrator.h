@@ -33,18 +33,38 @@ struct RawHit {
     uint32_t flags;  // bit0 backface, bit1 sphere, bit2 sphere exit
 };
 
-// Relative / absolute slack of the walk along the ray (kd_build.cpp, robustness rules): both children are visited when
-// the plane parameter lies within it of the node's interval, and the walk goes on while the next segment starts within it
-// of the best hit.  What it has to cover: Triangle::intersect in f32 accepts rays that pass a triangle's edge on the
-// OUTSIDE by s ~ 5 ... 50 x 2^-24 of the ray's length; when that edge lies in a split plane (the triangle lives on ONE side of
-// it) the ray point of the hit is on the wrong side and reaches the triangle's side only s / |d_axis| later along the ray.
-// 1e-5 (rounds 1-2) left rays with |d_axis| < 0.03 exposed: the grid-vs-KD check on config 5 found one in 2e10 casts
-// (profiles/r03_experiments.txt item 3).  1e-4 covers |d_axis| > 3e-3 for the same slop and costs 0.4 % of the frame
-// (1e-3: 2.1 %); fattening the primitives in the builder instead (PT_KD_PAD=1) closes the rest as well but costs 4-9 %.
-#ifndef PT_EXIT_REL
-#define PT_EXIT_REL 1.0001f
+// Slack of the walk along the ray (kd_build.cpp, robustness rules): both children are visited when the plane parameter lies
+// within it of the node's interval, and the walk goes on while the next segment starts within it of the best hit.  What it has
+// to cover: Triangle::intersect in f32 accepts rays that pass a triangle's edge on the OUTSIDE by a DISTANCE s ~ 5 ... 50 x 2^-24
+// of the ray's length.  A triangle lives only in the cells its own extent overlaps, so such a ray may run past the triangle's
+// cell: it leaves the enclosing box through a face of axis a - the END of the node's interval - and would have entered the
+// triangle's cell s / |d_a| later along the ray.  The slack of EVERY plane test therefore has to grow with 1 / |d_a| of whatever
+// axis bounds the interval, i.e. with the ray's largest |1 / d_axis|:
+//     relative slack of a ray = clamp(PT_SLACK_K * max |1 / d_axis|, PT_SLACK_MIN, PT_SLACK_MAX)          (exit_rel)
+// for the plane tests, the early exit and the restarts alike; PT_SLACK_K = 8e-6 (= 134 x 2^-24; rays have |d| = 1), capped at
+// PT_SLACK_MAX = 0.5 (a ray with a direction component below 1.6e-5 that runs along a plane within the slop for its whole length
+// is not covered - nor was it ever).  History: a constant 1e-5 (rounds 1-2) left rays with a component below 0.03 exposed - the
+// grid-vs-KD check on config 5 found one in 2e10 casts (d_x = 0.018, needs 1.6e-5 at a z plane); a constant 1e-4 (round 3, first
+// form) still left components of 3e-3 ... 0.03: tools/stress_paths.py found a camera ray with d_y = 0.011 through the shared edge
+// of two translucent triangles whose second hit the walk lost (needs 2.7e-4; profiles/r03_experiments.txt items 3, 13).
+// Fattening the primitives in the builder instead (PT_KD_PAD=1) costs 4-9 %.
+#ifndef PT_SLACK_MIN
+#define PT_SLACK_MIN 1e-5f
 #endif
+#ifndef PT_SLACK_K
+#define PT_SLACK_K 8e-6f
+#endif
+#define PT_SLACK_MAX 0.5f
 #define PT_EXIT_ABS 1e-6f
+PT_D float exit_rel(float ix, float iy, float iz) {
+    return fminf(PT_SLACK_MAX, fmaxf(PT_SLACK_MIN, PT_SLACK_K * fmaxf(fmaxf(fabsf(ix), fabsf(iy)), fabsf(iz))));
+}
+// where a cast that continues behind t_prev (alpha walk, next_hit) may start: the exit slack before it
+PT_D float restart_param(float t_prev, float ix, float iy, float iz) {
+    const float r = exit_rel(ix, iy, iz);
+    const float t = t_prev - (t_prev * r + PT_EXIT_ABS);
+    return t > 0.f ? t : 0.f;
+}
 
 // ---------------------------------------------------------------------------
 // KD-tree traversal (front to back).  `leaf(first_ref, n_refs)` tests the
@@ -59,6 +79,7 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
                       LocalCtr& lc, LeafFn&& leaf) {
     const float oa[3] = {o.x, o.y, o.z};
     const float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    const float xrel = exit_rel(inv[0], inv[1], inv[2]);
     // clip against the (padded) scene bounds
     float tmin = t_start, tmax = INFINITY;
 #pragma unroll
@@ -98,9 +119,10 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
             // A primitive touching the split plane lives on one side only (kd_build.cpp), so a
             // hit AT the plane must see both children: the one-child shortcuts keep a
             // relative epsilon of distance from the interval ends.
-            if (tplane > tmax * PT_EXIT_REL + PT_EXIT_ABS || tplane <= 0.f) {
+            const float rel = xrel;
+            if (tplane > tmax + (tmax * rel + PT_EXIT_ABS) || tplane <= 0.f) {
                 node = first;
-            } else if (tplane < tmin * (2.f - PT_EXIT_REL) - PT_EXIT_ABS) {
+            } else if (tplane < tmin - (tmin * rel + PT_EXIT_ABS)) {
                 node = second;
             } else {  // also taken when tplane is NaN: visit both (conservative)
                 st_node[sp] = second;
@@ -110,7 +132,12 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
                 // (never beyond the node's own interval: a plane within the slack PAST tmax must not inflate the near
                 // child's interval - nested, that compounds, the start reported for a later segment overtakes segments
                 // still on the stack, and the early exit below drops them: profiles/r03_experiments.txt item 3)
+                // ... nor before its start: a plane within the slack BEFORE tmin leaves the near child the point tmin and the
+                // far child - popped with the near child's end as its start - the whole interval
                 tmax = tplane < tmax ? tplane : tmax;
+#ifndef PT_NO_LOW_CLAMP
+                tmax = tmax > tmin ? tmax : tmin;
+#endif
             }
             continue;
         }
@@ -124,7 +151,7 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
             node = st_node[sp];
             tmax = st_tmax[sp];
             // everything from here on starts at tmin: stop when that is beyond the best hit
-            if (tmin * key_scale > limit * PT_EXIT_REL + PT_EXIT_ABS) return;
+            if (tmin * key_scale > limit + (limit * xrel + PT_EXIT_ABS)) return;
             break;
         }
     }
@@ -232,7 +259,7 @@ PT_D bool next_hit(const DevScene& S, f3 o, f3 d, float t_prev, uint32_t ord_pre
     best.pid = 0xffffffffu;
     float dlen = mag3(d);
     float key_scale = dlen < 1.0f ? dlen : 1.0f;              // key >= t * min(1, |d|)
-    float t_start = t_prev > 0.f ? t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f) * (2.f - PT_EXIT_REL) - PT_EXIT_ABS : 0.f;
+    float t_start = t_prev > 0.f ? restart_param(t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f), 1.0f / d.x, 1.0f / d.y, 1.0f / d.z) : 0.f;
     if (!(t_start > 0.f)) t_start = 0.f;
     float limit = INFINITY;
     kd_traverse<COUNT>(S, o, d, t_start, key_scale, limit, lc, [&](uint32_t first, uint32_t n) {

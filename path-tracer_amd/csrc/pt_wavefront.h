@@ -240,6 +240,7 @@ struct Trav {
 #if !WF_LEAN_TRAV
     f3 inv;
     float key_scale;
+    float rel;   // the ray's relative slack (exit_rel, pt_integrator.h)
 #endif
     float tmin, tmax;
     uint32_t node;
@@ -325,7 +326,9 @@ PT_D bool trav_start(const DevScene& S, Trav& T, f3 o, f3 d, float t_start) {
 #if !WF_LEAN_TRAV
     T.inv = inv3;
     float dlen = mag3(d);
-    T.key_scale = dlen < 1.0f ? dlen : 1.0f;
+    // (min(1, |d|) converts a ray parameter to key units; the early exit's relative slack is folded in: see trav_key_scale)
+    T.rel = exit_rel(inv3.x, inv3.y, inv3.z);
+    T.key_scale = (dlen < 1.0f ? dlen : 1.0f) / (1.0f + T.rel);
 #endif
     T.dneg = (d.x <= 0.f ? 1u : 0u) | (d.y <= 0.f ? 2u : 0u) | (d.z <= 0.f ? 4u : 0u);
     float tmin = t_start, tmax = INFINITY;
@@ -351,12 +354,21 @@ PT_D bool trav_start(const DevScene& S, Trav& T, f3 o, f3 d, float t_start) {
 
 // Move to the next stacked segment; false when the walk is over (stack empty or the segment
 // starts beyond `limit`, the best hit key so far).
-PT_D float trav_key_scale(const Trav& T) {   // key >= t * min(1, |d|) (next_hit)
+// key >= t * min(1, |d|) (next_hit), divided by 1 + the ray's exit slack (exit_rel): a segment that starts at tmin is
+// beyond a hit with key `limit` when tmin * trav_key_scale > limit + PT_EXIT_ABS
+PT_D float trav_key_scale(const Trav& T) {
 #if WF_LEAN_TRAV
     const float dlen = mag3(T.d);
-    return dlen < 1.0f ? dlen : 1.0f;
+    return (dlen < 1.0f ? dlen : 1.0f) / (1.0f + exit_rel(__builtin_amdgcn_rcpf(T.d.x), __builtin_amdgcn_rcpf(T.d.y), __builtin_amdgcn_rcpf(T.d.z)));
 #else
     return T.key_scale;
+#endif
+}
+PT_D float trav_rel(const Trav& T) {
+#if WF_LEAN_TRAV
+    return exit_rel(__builtin_amdgcn_rcpf(T.d.x), __builtin_amdgcn_rcpf(T.d.y), __builtin_amdgcn_rcpf(T.d.z));
+#else
+    return T.rel;
 #endif
 }
 PT_D float trav_inv_axis(const Trav& T, unsigned long long ax0, unsigned long long ax1) {   // 1 / d[axis] (v_rcp_f32, as trav_start)
@@ -371,7 +383,7 @@ PT_D bool trav_pop(Trav& T, const TravStack& st, float limit) {
     --T.sp;
     T.tmin = T.tmax;
     stack_get(st, T.sp, T.node, T.tmax);
-    return !(T.tmin * trav_key_scale(T) > limit * PT_EXIT_REL + PT_EXIT_ABS);
+    return !(T.tmin * trav_key_scale(T) > limit + PT_EXIT_ABS);
 }
 
 // Start a cast whose origin lies on a primitive (every ray after the camera ray: origin = hit point + normal * 1e-5,
@@ -413,12 +425,13 @@ PT_D bool trav_enter(const DevScene& S, Trav& T, const TravStack& st, f3 o, f3 d
                 const float tplane = (split - o_a) * i_a;
                 // the origin must be on the near side of the plane (or in it)
                 bad |= (w1 & 4u) ? (o_a > split ? 1u : 0u) : (o_a < split ? 1u : 0u);
-                const bool push = !(tplane < 0.f) & !(tplane > __builtin_fmaf(tmax, PT_EXIT_REL, PT_EXIT_ABS));   // (a NaN parameter: both)
+                const float rel = trav_rel(T);
+                const bool push = !(tplane < 0.f) & !(tplane > __builtin_fmaf(tmax, rel, tmax + PT_EXIT_ABS));   // (a NaN parameter: both)
                 last_far = w1 >> 3;
                 if (push) {
                     stack_push(st, sp, last_far, tmax);
                     ++sp;
-                    tmax = fminf(tplane, tmax);
+                    tmax = fmaxf(fminf(tplane, tmax), T.tmin);
                 }
             }
         }
@@ -476,13 +489,19 @@ PT_D uint32_t trav_step(const DevScene& S, Trav& T, const TravStack& st, float l
         const uint32_t pair = nd.y >> 2;  // children = pair (below), pair + 1 (above)
         const uint32_t second = pair + bf, first = pair + (bf ^ 1u);
         // the slack of the exit tests is the traversal's own (not reference arithmetic): fused
-        const bool only_first = (tplane > __builtin_fmaf(T.tmax, PT_EXIT_REL, PT_EXIT_ABS)) | (tplane <= 0.f);
-        const bool only_second = !only_first & (tplane < __builtin_fmaf(T.tmin, 2.f - PT_EXIT_REL, -PT_EXIT_ABS));
+        // (the ray's relative slack, exit_rel: it grows with the largest 1 / |d_axis|)
+        const float rel = trav_rel(T);
+        const bool only_first = (tplane > __builtin_fmaf(T.tmax, rel, T.tmax + PT_EXIT_ABS)) | (tplane <= 0.f);
+        const bool only_second = !only_first & (tplane < __builtin_fmaf(-T.tmin, rel, T.tmin - PT_EXIT_ABS));
         const bool both = !(only_first | only_second);  // also for a NaN plane parameter: conservative
         if (both) {
             stack_push(st, T.sp, second, T.tmax);
             ++T.sp;
-            T.tmax = fminf(tplane, T.tmax);   // (never beyond the node's own interval: see kd_traverse)
+#ifndef PT_NO_LOW_CLAMP
+            T.tmax = fmaxf(fminf(tplane, T.tmax), T.tmin);   // (never beyond the node's own interval, nor before its start: see kd_traverse)
+#else
+            T.tmax = fminf(tplane, T.tmax);
+#endif
         }
         T.node = only_second ? second : first;
         return WF_LANE_WALK;
@@ -596,8 +615,7 @@ PT_D void rederive_hit(const DevScene& S, const Trav& T, RawHit& best) {
 
 PT_D float next_start(float t_prev, f3 d) {  // where a continuation cast may start (see next_hit)
     float dlen = mag3(d);
-    float t_start = t_prev > 0.f ? t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f) * (2.f - PT_EXIT_REL) - PT_EXIT_ABS : 0.f;
-    return t_start > 0.f ? t_start : 0.f;
+    return t_prev > 0.f ? restart_param(t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f), 1.0f / d.x, 1.0f / d.y, 1.0f / d.z) : 0.f;
 }
 
 // HitRec packing: x = pid (bit 31 sphere), y = bits(key), z = bits(u), w = bits(v) with the
@@ -1190,8 +1208,9 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
             const float4 q0 = q[0], q1 = q[1];
             // from where k_wf_trace left the walk (less the slack a restarted walk backs off by, kd_traverse)
             const float walked = wf_list_progress(deferred, W.list_cap)[e];
-            const float t_start = walked > 0.f ? walked * (2.f - PT_EXIT_REL) - PT_EXIT_ABS : 0.f;
-            in_scene = trav_start(S, T, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), t_start > 0.f ? t_start : 0.f);
+            const f3 qd = mk3(q0.w, q1.x, q1.y);
+            const float t_start = walked > 0.f ? restart_param(walked, 1.0f / qd.x, 1.0f / qd.y, 1.0f / qd.z) : 0.f;
+            in_scene = trav_start(S, T, mk3(q0.x, q0.y, q0.z), qd, t_start);
             if (part == 0u) {   // ... with the best hit of the leaves behind that point
                 RawHit carried;
                 if (wf_load_carry(deferred, W.list_cap, e, carried)) best = carried;
@@ -1247,7 +1266,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
                         T.tmin = pool_tmin[group][slot];
                         T.tmax = pool_tmax[group][slot];
                         T.sp = 0;
-                        busy = !(T.tmin * trav_key_scale(T) > gkey * PT_EXIT_REL + PT_EXIT_ABS);
+                        busy = !(T.tmin * trav_key_scale(T) > gkey + PT_EXIT_ABS);
                     }
                     __builtin_amdgcn_wave_barrier();
                 }

@@ -441,6 +441,36 @@ def test_camera_grid_cull_is_exact(pta, gpu_scene_cache, name):
         assert np.array_equal(bits(acc), bits(full_acc[px])) and np.array_equal(rgb, full_rgb[px]), (name, rank)
 
 
+def test_walk_slack_grows_with_the_smallest_direction_component(pta, oracle):
+    """Found by tools/stress_paths.py (round 3): closed, textured, translucent generator scene 150 000 / seed 407 - sample 4 of
+    pixel (84, 135) of a 262 x 333 frame.  The camera ray (d_y = 0.011) passes through the shared edge of two translucent
+    triangles; f32 Moeller-Trumbore accepts both (8.429877 and 8.430029), the second lives across a split plane the ray only
+    reaches 2.7e-4 of its length later - the constant 1e-4 slack of the KD walk lost it, the alpha walk drew one random number
+    less and the path went elsewhere.  The slack is now the ray's own (pt_integrator.h exit_rel: it grows with the largest
+    1 / |d_axis|).  The ray through every cast implementation, and the frame on the three integrator paths."""
+    scene = pta.HostScene.generate_ps5(150000, seed=407, flags=7)
+    g = pta.GpuScene(scene)
+    ray = np.array([[float.fromhex(v) for v in ('0x1.3333340000000p-1', '0x1.3333340000000p+1', '0x1.2000000000000p+3',
+                                                 '-0x1.52427c0000000p-3', '0x1.683d480000000p-7', '-0x1.f8efcc0000000p-1')]], np.float32)
+    o_list, o_n = oracle.OracleScene(scene.desc, oracle.PTO_BRUTE_FORCE).trace_all(ray, 8)
+    assert o_n[0] == 3 and o_list["prim"][0, :3].tolist() == [57806, 57401, 149471]
+    g_list, g_n = g.trace_all(ray, 8)
+    assert np.array_equal(g_n, o_n) and np.array_equal(g_list["prim"], o_list["prim"]) and \
+        np.array_equal(bits(g_list["dist"]), bits(o_list["dist"]))
+    for mode in (0, 2):
+        w = g.trace_wavefront(ray, None, mode)
+        assert w["prim"][0] == 57806 and bits(w["dist"])[0] == bits(o_list["dist"])[0, 0], mode
+    prof = pta.Profile.make(262, 333, 7, 1, "FILMIC")
+    opts = dict(tile_w=64, tile_h=8)
+    rgb, acc = g.render(prof, pta.Opts.make(**opts))
+    for f in (pta.PT_FLAG_NO_GRIDS, pta.PT_FLAG_MEGAKERNEL):
+        rgb2, acc2 = g.render(prof, pta.Opts.make(flags=f, **opts))
+        assert np.array_equal(bits(acc), bits(acc2)) and np.array_equal(rgb, rgb2), f
+    px = 35454
+    o_rgb, o_acc, _ = oracle.OracleScene(scene.desc, oracle.PTO_BVH).render(prof, px, px + 1)
+    assert np.array_equal(bits(acc[px]), bits(o_acc[0]))
+
+
 def test_generated_scene_grid_and_kd_paths_agree(pta):
     for flags in (0, 1):   # opaque, translucent shells
         scene = pta.HostScene.generate_ps5(30000, seed=0, flags=flags)
