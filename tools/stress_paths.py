@@ -8,15 +8,22 @@ sys.path.insert(0, '.')
 import numpy as np
 import __graft_entry__ as e
 pta = e.load_package()
+orc = e.load_oracle()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
-cases = culled = 0
+cases = culled = with_oracle = 0
+last = t0
 while time.time() - t0 < budget:
+    if time.time() - last > 30:   # (a run on the GPU box must not stay silent)
+        print(f"... {cases} cases after {time.time() - t0:.0f} s", flush=True)
+        last = time.time()
     tris = int(rng.choice([600, 2000, 9000, 40000, 150000]))
     flags = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7]))
     seed = int(rng.integers(0, 1000))
-    g = pta.GpuScene(pta.HostScene.generate_ps5(tris, seed, flags), 0)
+    host_scene = pta.HostScene.generate_ps5(tris, seed, flags)
+    g = pta.GpuScene(host_scene, 0)
+    osc = None
     for _ in range(4):
         w, h = int(rng.integers(9, 700)), int(rng.integers(9, 400))
         prof = pta.Profile.make(w, h, int(rng.integers(1, 10)), int(rng.integers(0, 8)), str(rng.choice(["REINHARD", "FILMIC", "ACES"])))
@@ -34,5 +41,15 @@ while time.time() - t0 < budget:
                 print("MISMATCH", dict(tris=tris, flags=flags, seed=seed, w=w, h=h, spp=prof.samples, bounces=prof.bounces, path=f, **kw),
                       "pixels", bad[:10], len(bad))
                 sys.exit(1)
+        # small whole frames also against the CPU oracle (the restatement of the reference, pinned by its goldens)
+        if count == 1 and w * h * prof.samples <= 60000:
+            osc = osc or orc.OracleScene(host_scene.desc, orc.PTO_BVH)
+            o_rgb, o_acc, _ = osc.render(prof)
+            if not (np.array_equal(acc.view(np.uint32), o_acc.view(np.uint32)) and np.array_equal(rgb, o_rgb)):
+                bad = np.flatnonzero((acc.view(np.uint32) != o_acc.view(np.uint32)).reshape(len(acc), -1).any(1))
+                print("ORACLE MISMATCH", dict(tris=tris, flags=flags, seed=seed, w=w, h=h, spp=prof.samples, bounces=prof.bounces, **kw), "pixels", bad[:10], len(bad))
+                sys.exit(1)
+            with_oracle += 1
         cases += 1
+print(f"{with_oracle} of the cases also equal to the CPU oracle's frame")
 print(f"{cases} cases in {time.time() - t0:.0f} s, all three paths bit-identical; the camera-grid cull found empty blocks in {culled} of them")
