@@ -41,9 +41,11 @@ struct RawHit {
 // triangle's cell s / |d_a| later along the ray.  The slack of EVERY plane test therefore has to grow with 1 / |d_a| of whatever
 // axis bounds the interval, i.e. with the ray's largest |1 / d_axis|:
 //     relative slack of a ray = clamp(PT_SLACK_K * max |1 / d_axis|, PT_SLACK_MIN, PT_SLACK_MAX)          (exit_rel)
-// for the plane tests, the early exit and the restarts alike; PT_SLACK_K = 8e-6 (= 134 x 2^-24; rays have |d| = 1), capped at
-// PT_SLACK_MAX = 0.5 (a ray with a direction component below 1.6e-5 that runs along a plane within the slop for its whole length
-// is not covered - nor was it ever).  History: a constant 1e-5 (rounds 1-2) left rays with a component below 0.03 exposed - the
+// for the plane tests, the early exit and the restarts alike; PT_SLACK_K = 8e-6 (= 134 x 2^-24, 2.7 x the largest slop seen;
+// rays have |d| = 1), capped at PT_SLACK_MAX = 0.01: a ray with a direction component below 8e-4 (0.24 % of random directions)
+// keeps a band - 100 x narrower than round 3's first form left for 9 % of the rays.  Without the cap (0.5) those few rays visit
+// both children of almost every node: the longest cast of a frame 43 -> 151 rounds of k_wf_trace_wide, one shard of eight
+// -4 %, config 5 -4.6 %, the KD-tree-only pipeline -18 % (0.01: -0.5 %, -1.2 %, -5 %; profiles/r03_experiments.txt item 13).  History: a constant 1e-5 (rounds 1-2) left rays with a component below 0.03 exposed - the
 // grid-vs-KD check on config 5 found one in 2e10 casts (d_x = 0.018, needs 1.6e-5 at a z plane); a constant 1e-4 (round 3, first
 // form) still left components of 3e-3 ... 0.03: tools/stress_paths.py found a camera ray with d_y = 0.011 through the shared edge
 // of two translucent triangles whose second hit the walk lost (needs 2.7e-4; profiles/r03_experiments.txt items 3, 13).
@@ -54,7 +56,9 @@ struct RawHit {
 #ifndef PT_SLACK_K
 #define PT_SLACK_K 8e-6f
 #endif
-#define PT_SLACK_MAX 0.5f
+#ifndef PT_SLACK_MAX
+#define PT_SLACK_MAX 0.01f
+#endif
 #define PT_EXIT_ABS 1e-6f
 PT_D float exit_rel(float ix, float iy, float iz) {
     return fminf(PT_SLACK_MAX, fmaxf(PT_SLACK_MIN, PT_SLACK_K * fmaxf(fmaxf(fabsf(ix), fabsf(iy)), fabsf(iz))));
