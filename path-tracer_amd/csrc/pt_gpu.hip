@@ -2461,7 +2461,9 @@ int pt_get_cull_stats(const pt_scene* scene, uint32_t* n_blocks, uint32_t* n_emp
         if (scene->last_mask_blocks) {
             HIP_CHECK(hipSetDevice(scene->device));
             HIP_CHECK(hipDeviceSynchronize());
-            HIP_CHECK(hipMemcpy(n_empty, (const uint32_t*)scene->pipe.block_mask.p + scene->last_mask_blocks, 4, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> mask(scene->last_mask_blocks);
+            HIP_CHECK(hipMemcpy(mask.data(), scene->pipe.block_mask.p, mask.size() * 4, hipMemcpyDeviceToHost));
+            for (uint32_t m : mask) *n_empty += m != 0u;
         }
     });
 }
