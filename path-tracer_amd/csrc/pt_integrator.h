@@ -63,6 +63,12 @@ struct RawHit {
 PT_D float exit_rel(float ix, float iy, float iz) {
     return fminf(PT_SLACK_MAX, fmaxf(PT_SLACK_MIN, PT_SLACK_K * fmaxf(fmaxf(fabsf(ix), fabsf(iy)), fabsf(iz))));
 }
+// ... uncapped: the exact walker's (kd_traverse)
+PT_D float restart_param_exact(float t_prev, float ix, float iy, float iz) {
+    const float r = PT_SLACK_MIN + PT_SLACK_K * fmaxf(fmaxf(fabsf(ix), fabsf(iy)), fabsf(iz));
+    const float t = t_prev - (t_prev * r + PT_EXIT_ABS);   // (r = inf: -inf)
+    return t > 0.f ? t : 0.f;
+}
 // where a cast that continues behind t_prev (alpha walk, next_hit) may start: the exit slack before it
 PT_D float restart_param(float t_prev, float ix, float iy, float iz) {
     const float r = exit_rel(ix, iy, iz);
@@ -78,14 +84,22 @@ PT_D float restart_param(float t_prev, float ix, float iy, float iz) {
 // walk.  The stack holds (far child, its exit parameter); the entry parameter
 // of a popped node is the exit parameter of the segment just finished.
 // ---------------------------------------------------------------------------
+// This walker (the megakernel's, the test hooks', the shadow walk of the KD-tree-only paths) keeps the slack EXACTLY where the
+// argument above puts it, uncapped: every interval end remembers the relative slack of the axis whose plane (or scene-box
+// face) made it - K / |d_axis| - and a plane test adds the tested plane's own; the early exit uses the ray's largest.  It costs
+// a few instructions per step and a third stack column, which this path can afford; the wavefront walker (pt_wavefront.h
+// trav_step) uses the ray's largest slack, capped (exit_rel), for everything.  tools/stress_paths.py plays the two against each
+// other.
 template <bool COUNT, class LeafFn>
 PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_scale, float& limit,
                       LocalCtr& lc, LeafFn&& leaf) {
     const float oa[3] = {o.x, o.y, o.z};
     const float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    const float xrel = exit_rel(inv[0], inv[1], inv[2]);
+    const float ra[3] = {PT_SLACK_K * fabsf(inv[0]), PT_SLACK_K * fabsf(inv[1]), PT_SLACK_K * fabsf(inv[2])};   // (inf for d_axis = 0)
+    const float rmax = fmaxf(fmaxf(ra[0], ra[1]), ra[2]);
     // clip against the (padded) scene bounds
     float tmin = t_start, tmax = INFINITY;
+    float rel_lo = rmax, rel_hi = rmax;   // (a restart's t_start: no axis of its own)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float tn = (S.bounds_min[a] - oa[a]) * inv[a];
@@ -95,13 +109,19 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
             tn = tf;
             tf = tmp;
         }
-        tmin = tn > tmin ? tn : tmin;   // NaN (0 * inf) never narrows the interval
-        tmax = tf < tmax ? tf : tmax;
+        if (tn > tmin) {   // NaN (0 * inf) never narrows the interval
+            tmin = tn;
+            rel_lo = ra[a];
+        }
+        if (tf < tmax) {
+            tmax = tf;
+            rel_hi = ra[a];
+        }
     }
     if (tmin > tmax) return;
 
     uint32_t st_node[PT_KD_STACK];
-    float st_tmax[PT_KD_STACK];
+    float st_tmax[PT_KD_STACK], st_rel[PT_KD_STACK], st_tmin[PT_KD_STACK], st_rlo[PT_KD_STACK];
     int sp = 0;
     uint32_t node = 0;
     while (true) {
@@ -121,27 +141,43 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
             uint32_t first = below_first ? below : above;
             uint32_t second = below_first ? above : below;
             // A primitive touching the split plane lives on one side only (kd_build.cpp), so a
-            // hit AT the plane must see both children: the one-child shortcuts keep a
-            // relative epsilon of distance from the interval ends.
-            const float rel = xrel;
-            if (tplane > tmax + (tmax * rel + PT_EXIT_ABS) || tplane <= 0.f) {
+            // hit AT the plane must see both children: the one-child shortcuts keep the slack's
+            // distance from the interval ends (the end's own axis + the tested plane's).
+            const float rel_a = axis == 0 ? ra[0] : (axis == 1 ? ra[1] : ra[2]);
+            const float s_hi = rel_hi + rel_a + PT_SLACK_MIN, s_lo = rel_lo + rel_a + PT_SLACK_MIN;
+            // (a plane behind the origin is out of reach unless the ray runs along it: rel_a > 1 means |d_axis| < PT_SLACK_K)
+            if (tplane > tmax + (tmax * s_hi + PT_EXIT_ABS) || (tplane <= 0.f && !(rel_a > 1.0f))) {
                 node = first;
-            } else if (tplane < tmin - (tmin * rel + PT_EXIT_ABS)) {
+            } else if (tplane > 0.f && tplane < tmin - (tmin * s_lo + PT_EXIT_ABS)) {
                 node = second;
-            } else {  // also taken when tplane is NaN: visit both (conservative)
+            } else {  // also taken when tplane or a slack is NaN / inf: visit both (conservative)
                 st_node[sp] = second;
                 st_tmax[sp] = tmax;
-                ++sp;
+                st_rel[sp] = rel_hi;
                 node = first;
-                // (never beyond the node's own interval: a plane within the slack PAST tmax must not inflate the near
-                // child's interval - nested, that compounds, the start reported for a later segment overtakes segments
-                // still on the stack, and the early exit below drops them: profiles/r03_experiments.txt item 3)
-                // ... nor before its start: a plane within the slack BEFORE tmin leaves the near child the point tmin and the
-                // far child - popped with the near child's end as its start - the whole interval
-                tmax = tplane < tmax ? tplane : tmax;
-#ifndef PT_NO_LOW_CLAMP
-                tmax = tmax > tmin ? tmax : tmin;
-#endif
+                if (!(tplane > 0.f)) {
+                    // the ray runs ALONG a plane behind (or through) its origin: it stays on the near side, within the slop
+                    // of the far one, for the whole interval - both children get all of it
+                    st_tmin[sp] = tmin;
+                    st_rlo[sp] = rel_lo;
+                } else {
+                    // (never beyond the node's own interval: a plane within the slack PAST tmax must not inflate the near
+                    // child's interval - nested, that compounds, the start reported for a later segment overtakes segments
+                    // still on the stack, and the early exit below drops them: profiles/r03_experiments.txt item 3)
+                    // ... nor before its start: a plane within the slack BEFORE tmin leaves the near child the point tmin and
+                    // the far child the whole interval
+                    if (tplane < tmax) {
+                        tmax = tplane;
+                        rel_hi = rel_a;
+                    }
+                    if (!(tmax > tmin)) {
+                        tmax = tmin;
+                        rel_hi = rel_lo;
+                    }
+                    st_tmin[sp] = tmax;   // the far child starts where the near child ends
+                    st_rlo[sp] = rel_hi;
+                }
+                ++sp;
             }
             continue;
         }
@@ -151,11 +187,15 @@ PT_D void kd_traverse(const DevScene& S, f3 o, f3 d, float t_start, float key_sc
         while (true) {
             if (sp == 0) return;
             --sp;
-            tmin = tmax;
+            tmin = st_tmin[sp];
+            rel_lo = st_rlo[sp];
             node = st_node[sp];
             tmax = st_tmax[sp];
-            // everything from here on starts at tmin: stop when that is beyond the best hit
-            if (tmin * key_scale > limit + (limit * xrel + PT_EXIT_ABS)) return;
+            rel_hi = st_rel[sp];
+            // everything from here on starts at tmin or later - each segment by the slack of its own start, at most the ray's
+            // largest, earlier for a primitive the ray passes on the outside: stop when even that is beyond the best hit
+            // (a ray that runs along a plane - rmax > 1 - may have stacked segments out of order: no early exit for it)
+            if (!(rmax > 1.0f) && tmin * key_scale > limit + (limit * (rmax + PT_SLACK_MIN) + PT_EXIT_ABS)) return;
             break;
         }
     }
@@ -263,7 +303,7 @@ PT_D bool next_hit(const DevScene& S, f3 o, f3 d, float t_prev, uint32_t ord_pre
     best.pid = 0xffffffffu;
     float dlen = mag3(d);
     float key_scale = dlen < 1.0f ? dlen : 1.0f;              // key >= t * min(1, |d|)
-    float t_start = t_prev > 0.f ? restart_param(t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f), 1.0f / d.x, 1.0f / d.y, 1.0f / d.z) : 0.f;
+    float t_start = t_prev > 0.f ? restart_param_exact(t_prev * (dlen > 1.0f ? 1.0f / dlen : 1.0f), 1.0f / d.x, 1.0f / d.y, 1.0f / d.z) : 0.f;
     if (!(t_start > 0.f)) t_start = 0.f;
     float limit = INFINITY;
     kd_traverse<COUNT>(S, o, d, t_start, key_scale, limit, lc, [&](uint32_t first, uint32_t n) {
