@@ -1482,8 +1482,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         return e && *e ? atoi(e) != 0 : true;
     }();
     static const uint32_t wf_refill = [] {
+        // idle lanes that trigger a refill of a persistent wavefront.  Round 3, after the split shade pass and the slack
+        // change (config 3, trace stage): 2 / 4 / 6 / 8 / 12 / 16 / 24 / 32 -> 13.36 / 13.31 / 13.32 / 13.31 / 13.41 / 13.57 /
+        // 13.98 / 14.63 ms (16 was round 1's optimum)
         const char* e = getenv("PT_WF_REFILL");
-        return (uint32_t)(e && *e ? atoi(e) : 16);
+        return (uint32_t)(e && *e ? atoi(e) : 8);
     }();
     static const uint32_t wf_walk = [] {
         const char* e = getenv("PT_WF_WALK");
