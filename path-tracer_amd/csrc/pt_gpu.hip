@@ -1962,7 +1962,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                         else hipLaunchKernelGGL((k_og_shadow_offgrid<false, false>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, PT_OGS_ARGS);
                         HIP_CHECK(hipGetLastError());
                     } else if (use_light_grids) {   // every light a point light with a grid: plain grid-stride kernel
-                        const dim3 g((uint32_t)s.n_cu * 16u);
+                        static const uint32_t ogs_blocks = [] {   // workgroups per CU of k_og_shadow's grid-stride launch
+                            const char* e = getenv("PT_OGS_BLOCKS");
+                            return (uint32_t)(e && *e ? atoi(e) : 16);
+                        }();
+                        const dim3 g((uint32_t)s.n_cu * std::max(1u, ogs_blocks));
 #define PT_LAUNCH_OGSH(A, C)                                                                                   \
     do {                                                                                                       \
         if (s.ortho_light_grids) hipLaunchKernelGGL((k_og_shadow<A, C, true>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS); \
