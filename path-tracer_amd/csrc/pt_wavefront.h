@@ -1461,6 +1461,9 @@ PT_D bool wf_light_is_moot(const DevLight& L, f3 term, f3 surface_pos) {
 // 132 B of its state per lane in scratch: 18.66 ms against 17.09 ms at 3 (and 21.3 ms at 2) on config 3.
 #define WF_SHADE_GRID_WAVES 3
 #endif
+#ifndef WF_SHADE_GRID_WAVES_ALPHA
+#define WF_SHADE_GRID_WAVES_ALPHA WF_SHADE_GRID_WAVES   // (translucent scenes, 88 B of scratch at 3: 2 waves measured worse, item 17)
+#endif
 // GRID (origin grids, pt_grid.h): 0 - none: direct light goes through the shadow queue and k_wf_shadow / k_og_shadow;
 // 1 - every light is a point light with a grid: get_light_info (mod.rs:281-333) is evaluated HERE, light after
 //     light, so a surface costs no shadow record, no contrib entries and no colour patch (190 B of queue traffic
@@ -1472,7 +1475,7 @@ PT_D bool wf_light_is_moot(const DevLight& L, f3 term, f3 surface_pos) {
 //     the words of bounces 1 and 2 (plane 1 of the RNG planes; a path has made at least four draws by then).
 // GRIDX = GRID + 4 * DIRL; DIRL: some light is directional (orthographic grid branch of og_light_radiance compiled in).
 template <bool ALPHA, bool COUNT, bool PRIMARY, int GRIDX>
-__global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? WF_SHADE_GRID_WAVES : WF_SHADE_WAVES) void k_wf_shade(DevScene S, WfParams W,
+__global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WAVES_ALPHA : WF_SHADE_GRID_WAVES) : WF_SHADE_WAVES) void k_wf_shade(DevScene S, WfParams W,
                                                   const uint32_t* __restrict__ tile_offsets,
                                                   const float4* __restrict__ queue_in, const uint4* __restrict__ hits,
                                                   const uint4* rng_planes,
