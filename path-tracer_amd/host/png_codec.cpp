@@ -13,10 +13,13 @@
 // "parity unpinned" (SURVEY §4).
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <fstream>
 #include <vector>
 
@@ -251,10 +254,56 @@ int pth_png_write_rgb8(const char* path, uint32_t w, uint32_t h, const uint8_t* 
             raw[(stride + 1) * y] = 0;
             memcpy(&raw[(stride + 1) * y + 1], rgb + stride * y, stride);
         }
-        uLongf clen = compressBound(raw.size());
-        std::vector<uint8_t> comp(clen);
-        if (compress2(comp.data(), &clen, raw.data(), raw.size(), 6) != Z_OK)
-            pth::fail(PT_ERR_IO, "PNG deflate failed");
+        // The zlib stream of IDAT, deflated in parallel (as pigz does): bands of rows compressed independently as raw
+        // deflate, every band but the last ended with a sync flush (an empty stored block: byte-aligned), concatenated
+        // behind one zlib header, the Adler-32 of the whole combined from the bands'.  A noisy 1080p render took 380 ms at
+        // level 6 on one core - ten frames' worth of rendering; level 1 in bands takes ~15 ms on the MI355X host.
+        const size_t band_rows = 32, n_bands = (h + band_rows - 1) / band_rows;
+        std::vector<std::vector<uint8_t>> parts(n_bands);
+        std::vector<uLong> adlers(n_bands);
+        std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};
+        auto work = [&]() {
+            for (size_t b; (b = next.fetch_add(1)) < n_bands;) {
+                const size_t r0 = b * band_rows, r1 = std::min<size_t>(h, r0 + band_rows);
+                const uint8_t* src = raw.data() + (stride + 1) * r0;
+                const size_t len = (stride + 1) * (r1 - r0);
+                adlers[b] = adler32(adler32(0L, Z_NULL, 0), src, (uInt)len);
+                z_stream z{};
+                if (deflateInit2(&z, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+                    failed = true;
+                    continue;
+                }
+                std::vector<uint8_t>& out_b = parts[b];
+                out_b.resize(deflateBound(&z, (uLong)len) + 16);
+                z.next_in = const_cast<Bytef*>(src);
+                z.avail_in = (uInt)len;
+                z.next_out = out_b.data();
+                z.avail_out = (uInt)out_b.size();
+                const int rc = deflate(&z, b + 1 == n_bands ? Z_FINISH : Z_SYNC_FLUSH);
+                if ((b + 1 == n_bands ? rc != Z_STREAM_END : rc != Z_OK) || z.avail_in != 0) failed = true;
+                out_b.resize(out_b.size() - z.avail_out);
+                deflateEnd(&z);
+            }
+        };
+        {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const size_t n_threads = std::min<size_t>({(size_t)hw, (size_t)32, n_bands});
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+        }
+        if (failed) pth::fail(PT_ERR_IO, "PNG deflate failed");
+        std::vector<uint8_t> comp = {0x78, 0x01};
+        uLong adler = adler32(0L, Z_NULL, 0);
+        for (size_t b = 0; b < n_bands; ++b) {
+            comp.insert(comp.end(), parts[b].begin(), parts[b].end());
+            const size_t r0 = b * band_rows, r1 = std::min<size_t>(h, r0 + band_rows);
+            adler = adler32_combine(adler, adlers[b], (z_off_t)((stride + 1) * (r1 - r0)));
+        }
+        for (int k = 3; k >= 0; --k) comp.push_back((uint8_t)(adler >> (8 * k)));
+        const size_t clen = comp.size();
         std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
         std::vector<uint8_t> ihdr;
         pth::put32(ihdr, w);
