@@ -25,6 +25,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <charconv>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -129,6 +130,13 @@ public:
         while (p_ < end_ && ((*p_ >= '0' && *p_ <= '9') || *p_ == '.' || *p_ == 'e' ||
                              *p_ == 'E' || *p_ == '+' || *p_ == '-'))
             ++p_;
+        // std::from_chars (correctly rounded like strtod, a third of its time: a 500 000-triangle ISF holds 12 M numbers - 0.5 of
+        // the 0.8 s it took to load) for what it accepts; everything else - range errors, odd spellings - goes the old way
+        {
+            double fast;
+            const std::from_chars_result r = std::from_chars(s, p_, fast);
+            if (r.ec == std::errc() && r.ptr == p_) return fast;
+        }
         // strtod needs a terminated buffer; numbers are short.
         char buf[80];
         size_t n = (size_t)(p_ - s);
