@@ -264,6 +264,7 @@ int pth_png_write_rgb8(const char* path, uint32_t w, uint32_t h, const uint8_t* 
         std::atomic<size_t> next{0};
         std::atomic<bool> failed{false};
         auto work = [&]() {
+            try {
             for (size_t b; (b = next.fetch_add(1)) < n_bands;) {
                 const size_t r0 = b * band_rows, r1 = std::min<size_t>(h, r0 + band_rows);
                 const uint8_t* src = raw.data() + (stride + 1) * r0;
@@ -284,6 +285,9 @@ int pth_png_write_rgb8(const char* path, uint32_t w, uint32_t h, const uint8_t* 
                 if ((b + 1 == n_bands ? rc != Z_STREAM_END : rc != Z_OK) || z.avail_in != 0) failed = true;
                 out_b.resize(out_b.size() - z.avail_out);
                 deflateEnd(&z);
+            }
+            } catch (...) {   // (out of memory in a band's buffer: a thread must not end the process)
+                failed = true;
             }
         };
         {
