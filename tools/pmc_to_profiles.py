@@ -7,8 +7,10 @@ profiles/<tag>_pmc.json and refresh profiles/latest_traffic.json (read by bench.
 import csv, glob, json, sys
 from collections import defaultdict
 
-src, tag = sys.argv[1], sys.argv[2]
-workload = [int(v) for v in sys.argv[3:9]]
+no_latest = "--no-latest" in sys.argv   # (a workload other than the headline's: profiles/latest_traffic.json stays)
+argv = [a for a in sys.argv if a != "--no-latest"]
+src, tag = argv[1], argv[2]
+workload = [int(v) for v in argv[3:9]]
 acc = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(int)
 for path in sorted(glob.glob(f"{src}/pass*/**/*counter_collection.csv", recursive=True)):
@@ -57,7 +59,8 @@ setup = {k: out.pop(k) for k in list(out) if k.startswith("ogb::")}
 json.dump({"workload": workload, "kernels": out, "setup_kernels": setup}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 dominant = max(out, key=lambda k: out[k]["kernel_ms_profiled"])
 t = out[dominant]
-json.dump({"workload": workload, "kernel": dominant, "hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
+if not no_latest:
+  json.dump({"workload": workload, "kernel": dominant, "hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
            "tcp_accesses_per_cu_cycle": t["tcp_accesses_per_cu_cycle"],
            "valu_insts_per_cu_cycle": t["valu_insts_per_cu_cycle"],
            "active_lanes_per_valu_inst": t["active_lanes_per_valu_inst"],

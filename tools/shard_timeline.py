@@ -1,6 +1,7 @@
 """Kernel timeline of ONE shard's frame (where the fixed per-frame cost of a 1/N shard sits):
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 tools/shard_timeline.py run [--shards 8]
     python tools/shard_timeline.py show gpurun_out/tl [--frames 6]
+(workload flags as tools/shard_times.py: --width --height --bounces --tonemap --scene-flags --tris --spp)
 'run' renders shard 0 of N six times (plain options, no timing events); 'show' takes the last frame from the trace
 and prints every launch with its start offset, duration and the idle gap before it on its stream."""
 import argparse, csv, glob, sys
@@ -12,14 +13,19 @@ ap.add_argument('--shards', type=int, default=8)
 ap.add_argument('--frames', type=int, default=6)
 ap.add_argument('--spp', type=int, default=128)
 ap.add_argument('--tris', type=int, default=500000)
+ap.add_argument('--width', type=int, default=1920)
+ap.add_argument('--height', type=int, default=1080)
+ap.add_argument('--bounces', type=int, default=5)
+ap.add_argument('--tonemap', default='FILMIC')
+ap.add_argument('--scene-flags', type=int, default=0)
 a = ap.parse_args()
 if a.what == 'run':
     import torch
     torch.zeros(1, device='cuda')
     import __graft_entry__ as e
     pta = e.load_package()
-    g = pta.GpuScene(pta.HostScene.generate_ps5(a.tris, 0), 0)
-    prof = pta.Profile.make(1920, 1080, a.spp, 5, "FILMIC")
+    g = pta.GpuScene(pta.HostScene.generate_ps5(a.tris, 0, a.scene_flags), 0)
+    prof = pta.Profile.make(a.width, a.height, a.spp, a.bounces, a.tonemap)
     opts = pta.Opts.make(flags=0, shard_rank=0, shard_count=a.shards, tile_w=32, tile_h=32)
     npx = len(pta.local_pixel_map(prof, opts))
     rgb = torch.empty(npx * 3, dtype=torch.uint8, device='cuda')
