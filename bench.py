@@ -441,7 +441,7 @@ def main():
                        "parallelism": f"{world} x tile-sharded (32x32 interleaved)" + (
                            "" if world == 1 else ", RCCL all-gather of u8 framebuffer" if args.backend == "nccl"
                            else f", {args.backend} all-gather through host memory (REHEARSAL on {len(set(devices))} GPU(s), not an RCCL run)"),
-                       "kd": {k: info[k] for k in ("n_prims", "n_kd_nodes", "n_kd_leaves", "n_leaf_refs", "kd_depth", "n_edge_prims")},
+                       "kd": {k: info[k] for k in ("n_prims", "n_kd_nodes", "n_kd_leaves", "n_leaf_refs", "kd_depth")},
                        "origin_grids": {k: info[k] for k in ("cam_grid_res", "light_grids", "grid_refs")},
                        "setup_seconds": round(setup_s, 2), "kd_build_seconds": round(info["kd_build_seconds"], 2),
                        "grid_build_seconds": round(info["grid_build_seconds"], 2),

@@ -306,6 +306,8 @@ typedef struct pt_counters {
     uint64_t grid_tris;            /* of tris_tested: made through origin grids (camera / point lights) */
     uint64_t bounce0_cam_tris;     /* of bounce0_tris: the camera casts (also part of trace_tris)       */
     uint64_t deferred_casts;       /* closest-hit casts finished by k_wf_trace_wide (drain phase of k_wf_trace) */
+    uint64_t exact_casts;          /* closest-hit casts k_wf_trace left to k_wf_trace_exact: rays whose direction has a component
+                                    * below 8e-4, which the wavefront walker's slack does not cover (csrc/pt_integrator.h) */
 } pt_counters;
 
 int pt_get_timing(const pt_scene* scene, pt_timing* out);
@@ -332,8 +334,6 @@ typedef struct pt_scene_info {
     uint32_t light_grids;     /* lights whose shadow rays use a grid (all or none)    */
     uint64_t grid_refs;       /* list entries of all grids                            */
     float grid_build_seconds;
-    uint32_t n_edge_prims;    /* primitives close to an edge of the scene's bounding box: a hit on one of them is
-                                 subject to kdtree-ray's f32 slab test (csrc/pt_integrator.h scene_slab)        */
 } pt_scene_info;
 int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out);
 
@@ -358,7 +358,8 @@ int pt_trace_rays(const pt_scene* scene, const float* rays, uint64_t n, pt_hit* 
 
 /* The first entry of ray_cast() through the wavefront integrator's own cast kernel (k_wf_trace; the rays of bounces
  * >= 1 of every frame go through it).  mode bit 0: start at the home node of the primitive the ray leaves
- * (start_prims[i], entry lists); bit 1: hand every cast to the cooperative kernel k_wf_trace_wide. */
+ * (start_prims[i], entry lists); bit 1: hand every cast to the cooperative kernel k_wf_trace_wide; bit 2 (study switch):
+ * WITHOUT the hand-over of the rays the walker's slack does not cover (a direction component below 8e-4) to k_wf_trace_exact. */
 int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint32_t* start_prims, uint64_t n,
                             uint32_t mode, pt_hit* out);
 

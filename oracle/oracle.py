@@ -38,6 +38,8 @@ def lib():
         L.pto_eval_math.argtypes = [C.c_int, vp, C.c_uint64, vp]
         L.pto_primary_ray.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp]
         L.pto_path_rays.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, vp]
+        L.pto_scene_slab_study_begin.argtypes = [vp, C.c_int]
+        L.pto_scene_slab_study.argtypes = [vp, vp]
         L.pto_max_threads.restype = C.c_int
         L.pto_last_error.restype = C.c_char_p
         _lib = L
@@ -93,6 +95,16 @@ class OracleScene:
         _check(lib().pto_trace_rays_all(self.handle, rays.ctypes.data, len(rays), max_hits, out.ctypes.data,
                                         counts.ctypes.data))
         return out, counts
+
+    def slab_study_begin(self, on=True):
+        """Study hook: casts the slab test rejects are searched for hits anyway and counted (slab_study)."""
+        _check(lib().pto_scene_slab_study_begin(self.handle, 1 if on else 0))
+
+    def slab_study(self):
+        """(casts the slab test rejected although they had hits, of those: origin strictly inside the scene's box)."""
+        out = np.zeros(2, np.uint64)
+        _check(lib().pto_scene_slab_study(self.handle, out.ctypes.data))
+        return int(out[0]), int(out[1])
 
     def primary_ray(self, profile, pixel, sample):
         out = np.zeros(6, np.float32)

@@ -17,6 +17,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -206,6 +207,10 @@ struct pto_scene {
     std::vector<uint32_t> prim_first;  // per model: first global primitive id
     std::vector<uint32_t> prim_model;  // per primitive: model index
     std::vector<uint8_t> hidden;       // study hook (pto_scene_hide_prims): primitives no candidate filter returns
+    // study hook (pto_scene_slab_study_begin): casts the slab test rejects although they have hits, and how many of those start
+    // STRICTLY inside the scene's box (the product runs the slab test only for the other origins: must stay 0)
+    bool slab_study = false;
+    mutable std::atomic<uint64_t> slab_rejected_with_hits{0}, slab_rejected_inside{0};
     std::vector<Box> model_box;        // Model::bound() — internal/model.rs:76-86 (exact, unpadded)
     Box scene_box;                     // their union = the space of the scene's KDTree (internal/mod.rs:42)
     int mode;
@@ -496,7 +501,8 @@ void ray_cast(const pto_scene& s, const Ray& ray, CastScratch& sc, uint64_t* num
         g_ray_log->insert(g_ray_log->end(), r6, r6 + 6);
     }
     sc.hits.clear();
-    if (!(s.mode & PTO_NO_SCENE_SLAB) && !kdtree_ray_slab(s.scene_box, ray)) return;  // no space passes: no candidates
+    const bool rejected = !(s.mode & PTO_NO_SCENE_SLAB) && !kdtree_ray_slab(s.scene_box, ray);
+    if (rejected && !s.slab_study) return;  // no space passes: no candidates
     if (!(s.mode & PTO_BVH)) {
         uint32_t n = (uint32_t)s.prim_model.size();
         for (uint32_t p = 0; p < n; ++p) test_prim(s, p, ray, sc.hits, numeric_errors);
@@ -513,6 +519,17 @@ void ray_cast(const pto_scene& s, const Ray& ray, CastScratch& sc, uint64_t* num
     sc.hits.resize(w);
     std::stable_sort(sc.hits.begin(), sc.hits.end(),
                      [](const Hit& a, const Hit& b) { return a.dist < b.dist; });
+    if (rejected) {   // study: what the product - which tests the box only for marked hits - would have seen
+        if (!sc.hits.empty()) {
+            s.slab_rejected_with_hits.fetch_add(1, std::memory_order_relaxed);
+            // (the product's rule, csrc/pt_integrator.h hit_passes_slab: the box is tested unless the origin is strictly inside it)
+            const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z};
+            bool inside = true;
+            for (int a = 0; a < 3; ++a) inside = inside && o[a] > s.scene_box.mn[a] && o[a] < s.scene_box.mx[a];
+            if (inside) s.slab_rejected_inside.fetch_add(1, std::memory_order_relaxed);
+        }
+        sc.hits.clear();   // no space passes: no candidates
+    }
 }
 
 // ------------------------------------------------------------------ materials
@@ -970,6 +987,21 @@ void pto_scene_destroy(pto_scene* s) { delete s; }
 
 // Study hook for the white_furnace_direct investigation: primitives with mask[p] != 0 are treated as if the
 // candidate filter (kdtree-ray in the reference) never returned them.  n must be the primitive count; n == 0 clears.
+int pto_scene_slab_study_begin(pto_scene* s, int on) {
+    if (!s) return set_err(PT_ERR_INVALID, "pto_scene_slab_study_begin: null argument");
+    s->slab_study = on != 0;
+    s->slab_rejected_with_hits = 0;
+    s->slab_rejected_inside = 0;
+    return PT_OK;
+}
+
+int pto_scene_slab_study(const pto_scene* s, uint64_t* out2) {
+    if (!s || !out2) return set_err(PT_ERR_INVALID, "pto_scene_slab_study: null argument");
+    out2[0] = s->slab_rejected_with_hits.load();
+    out2[1] = s->slab_rejected_inside.load();
+    return PT_OK;
+}
+
 int pto_scene_hide_prims(pto_scene* s, const uint8_t* mask, uint64_t n) {
     if (n == 0) { s->hidden.clear(); return PT_OK; }
     if (n != s->prim_model.size()) return set_err(PT_ERR_INVALID, "hide_prims: %llu masks for %zu primitives",

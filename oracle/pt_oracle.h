@@ -42,6 +42,14 @@ void pto_scene_destroy(pto_scene* s);
  * candidate filter.  n = primitive count, or 0 to clear. */
 int pto_scene_hide_prims(pto_scene* s, const uint8_t* mask, uint64_t n);
 
+/* Study hook (slab test): the PRODUCT runs kdtree-ray's slab test only for casts whose origin is not strictly
+ * inside the scene's bounding box (csrc/pt_integrator.h hit_passes_slab: for an origin strictly inside, the f32 test cannot
+ * fail).  With the study on, every cast the oracle's slab test rejects is searched for hits anyway (the result stays "no
+ * hits"): out2[0] = casts rejected although they had hits, out2[1] = of those, casts whose origin IS strictly inside the
+ * box - the product would have kept their hit; must be 0. */
+int pto_scene_slab_study_begin(pto_scene* s, int on);
+int pto_scene_slab_study(const pto_scene* s, uint64_t* out2);
+
 typedef struct pto_stats {
     uint64_t samples;
     uint64_t segments;      /* ray_cast calls from render_pixel                */

@@ -107,7 +107,7 @@ class Counters(C.Structure):
                                           "tris_tested", "shaded_hits", "rng_draws", "restarts",
                                           "max_nodes_per_cast", "casts_over_1k_nodes", "trace_nodes", "trace_tris",
                                           "shadow_skipped", "bounce0_hits", "bounce0_shadow_rays", "bounce0_tris",
-                                          "grid_tris", "bounce0_cam_tris", "deferred_casts")]
+                                          "grid_tris", "bounce0_cam_tris", "deferred_casts", "exact_casts")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -118,7 +118,7 @@ class SceneInfo(C.Structure):
                 ("n_leaf_refs", C.c_uint64), ("kd_depth", C.c_uint32), ("has_translucent", C.c_uint32),
                 ("kd_build_seconds", C.c_float), ("upload_seconds", C.c_float), ("device_bytes", C.c_uint64),
                 ("cam_grid_res", C.c_uint32), ("light_grids", C.c_uint32), ("grid_refs", C.c_uint64),
-                ("grid_build_seconds", C.c_float), ("n_edge_prims", C.c_uint32)]
+                ("grid_build_seconds", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -9,12 +9,10 @@
 //               128-B line); the host builder's DFS array (include/pthost.h) is permuted on upload
 //   leaf_prims  48 B / leaf reference, stored leaf after leaf so a leaf's
 //               primitives are one contiguous, 16-B aligned run:
-//                 q0 = (v0.x, v0.y, v0.z, bits(prim_id | kind<<31 | edge<<30))
+//                 q0 = (v0.x, v0.y, v0.z, bits(prim_id | kind<<31))
 //                 q1 = (e1.x, e1.y, e1.z, e2.x)      e1 = v1 - v0 (f32, as
 //                 q2 = (e2.y, e2.z, 0, 0)            triangle.rs:43-44 computes it)
 //               spheres: q0 = (c.x, c.y, c.z, bits(prim | 1<<31)), q1.x = radius
-//               edge: the primitive comes close to an edge of the scene's bounding box, a cast that ends on it is
-//               subject to kdtree-ray's slab test (scene_slab, pt_integrator.h)
 //   prim_attr   64 B / primitive, indexed by global primitive id (shading only):
 //                 a0 = (n0.xyz, uv0.x) a1 = (n1.xyz, uv0.y) a2 = (n2.xyz, uv1.x)
 //                 a3 = (uv1.y, uv2.x, uv2.y, bits(model))
@@ -31,7 +29,6 @@
 #include "ptgpu.h"
 
 #define PT_PRIM_SPHERE 0x80000000u
-#define PT_PRIM_EDGE 0x40000000u     // the primitive comes close to an edge of the scene's bounding box (scene_slab)
 #define PT_PRIM_INDEX(pid) ((pid) & 0x3fffffffu)
 #define PT_KD_STACK 64
 
@@ -136,7 +133,7 @@ static inline void pt_fastdiv_make(uint32_t d, uint32_t (&ms)[2]) {
 struct DevCounters {
     unsigned long long samples, segments, shadow_rays, nodes_visited, tris_tested, shaded_hits, rng_draws,
         restarts, max_nodes_per_cast, casts_over_1k_nodes, trace_nodes, trace_tris, shadow_skipped,
-        bounce0_hits, bounce0_shadow_rays, bounce0_tris, grid_tris, bounce0_cam_tris, deferred_casts;
+        bounce0_hits, bounce0_shadow_rays, bounce0_tris, grid_tris, bounce0_cam_tris, deferred_casts, exact_casts;
     unsigned long long stamps[8];  // diagnostics: phase cycles of a -DWF_STAMPS build; else [0,1,3,4,5] rounds / steps / time of k_wf_trace_wide
     unsigned long long cast_hist[16];  // k_wf_trace casts by nodes visited, 64 per bin (PT_DEBUG_HIST prints it)
 #ifdef WF_EXIT_TIMES

@@ -38,6 +38,7 @@
 #include "pt_integrator.h"
 #include "pt_wavefront.h"
 #include "pt_grid_kernels.h"
+#include "pt_sort.h"
 #include "pt_grid_build.h"
 #include "pthost.h"
 
@@ -495,9 +496,10 @@ struct pt_scene {
     // The queues of the chunk of work items in flight.  The shadow casts of bounce b run on a side stream
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
-        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid, deferred, block_mask;
-        hipStream_t side = nullptr, side_rng = nullptr, side_wide = nullptr;
-        hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr, ev_trace = nullptr, ev_wide = nullptr;
+        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid, deferred, exact[2], block_mask, sort_keys[2], sort_vals[2], sort_temp;
+        hipStream_t side = nullptr, side_rng = nullptr, side_wide = nullptr, side_exact = nullptr;
+        hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr, ev_trace = nullptr, ev_wide = nullptr,
+                   ev_exact = nullptr, ev_exact_go = nullptr;
     };
     mutable WfPipe pipe;
     mutable int trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
@@ -519,8 +521,9 @@ struct pt_scene {
         if (capture_stream) (void)hipStreamDestroy(capture_stream);
         for (void* p : allocations) (void)hipFree(p);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {pipe.ev_shade, pipe.ev_shadow, pipe.ev_rng, pipe.ev_chunk, pipe.ev_trace, pipe.ev_wide})
+        for (hipEvent_t e : {pipe.ev_shade, pipe.ev_shadow, pipe.ev_rng, pipe.ev_chunk, pipe.ev_trace, pipe.ev_wide, pipe.ev_exact, pipe.ev_exact_go})
             if (e) (void)hipEventDestroy(e);
+        if (pipe.side_exact) (void)hipStreamDestroy(pipe.side_exact);
         if (pipe.side) (void)hipStreamDestroy(pipe.side);
         if (pipe.side_rng) (void)hipStreamDestroy(pipe.side_rng);
         if (pipe.side_wide) (void)hipStreamDestroy(pipe.side_wide);
@@ -684,24 +687,18 @@ void prep_create(const pt_scene_desc& d, pt_prep& P, pt_scene* early = nullptr, 
         }
     }
     // ---- kdtree-ray's slab test (scene_slab, pt_integrator.h): the exact bounding box of the scene - the union of
-    // Model::bound() (model.rs:76-86: the positions' bounds for a mesh, centre -+ radius for a sphere) - and the mark
-    // on every primitive that comes close to one of its EDGES.  Only a ray that clips an edge of the box within the
-    // rounding of the test (~1e-7 of its length) can fail it while hitting something, and whatever it hits then lies
-    // within that distance (plus the slop of the intersection tests) of the edge.  delta = 1e-4 x (the largest distance a
-    // ray of this scene can cover: the box diagonal, or from the camera to its far corner) is a hundred times that; a
-    // primitive within delta of an edge has its own bounds within delta of the two faces that meet there.
+    // Model::bound() (model.rs:76-86: the positions' bounds for a mesh, centre -+ radius for a sphere).  A cast whose origin
+    // is not strictly inside it runs the test once, at its end (hit_passes_slab).
     {
         DevScene& D = P.dev;
         for (int a = 0; a < 3; ++a) {
             D.slab_min[a] = INFINITY;
             D.slab_max[a] = -INFINITY;
         }
-        std::vector<float> pmn(n_prims * 3), pmx(n_prims * 3);
-        uint64_t q = 0;
         for (uint32_t m = 0; m < d.n_models; ++m) {
             const pt_model& mo = d.models[m];
             const uint32_t cnt = mo.kind == PT_MODEL_MESH ? mo.tri_count : 1u;
-            for (uint32_t t = 0; t < cnt; ++t, ++q) {
+            for (uint32_t t = 0; t < cnt; ++t) {
                 for (int a = 0; a < 3; ++a) {
                     float lo, hi;
                     if (mo.kind == PT_MODEL_MESH) {
@@ -712,39 +709,14 @@ void prep_create(const pt_scene_desc& d, pt_prep& P, pt_scene* early = nullptr, 
                         lo = mo.center[a] - mo.radius;
                         hi = mo.center[a] + mo.radius;
                     }
-                    pmn[q * 3 + a] = lo;
-                    pmx[q * 3 + a] = hi;
                     D.slab_min[a] = fminf(D.slab_min[a], lo);
                     D.slab_max[a] = fmaxf(D.slab_max[a], hi);
                 }
             }
         }
-        double diag2 = 0, cam2 = 0;
-        for (int a = 0; a < 3; ++a) {
-            const double w = (double)D.slab_max[a] - D.slab_min[a], c = d.camera.transform[12 + a];
-            const double far = std::max(std::fabs(c - D.slab_min[a]), std::fabs(c - D.slab_max[a]));
-            diag2 += w * w;
-            cam2 += far * far;
-        }
-        const double reach = std::sqrt(std::max(diag2, cam2));
-        const float delta = std::isfinite(reach) ? (float)(1e-4 * reach) : INFINITY;
         if (n_prims >= (1ull << 28)) fail(PT_ERR_UNSUPPORTED, "more than 2^28 primitives");   // (pack_hit's index bits)
-        uint64_t marked = 0;
-        for (uint64_t k = 0; k < n_prims; ++k) {
-            int near_faces = 0;
-            for (int a = 0; a < 3; ++a)
-                if (!(pmn[k * 3 + a] > D.slab_min[a] + delta) || !(pmx[k * 3 + a] < D.slab_max[a] - delta)) ++near_faces;
-            if (near_faces >= 2) {
-                uint32_t w;
-                memcpy(&w, &pos[k * 3].w, 4);
-                w |= PT_PRIM_EDGE;
-                memcpy(&pos[k * 3].w, &w, 4);
-                ++marked;
-            }
-        }
-        P.info.n_edge_prims = (uint32_t)std::min<uint64_t>(marked, 0xffffffffu);
     }
-    section("primitive arrays, edge marks");
+    section("primitive arrays, scene box");
     const uint64_t n_prims_early = pth_prim_count(&d);
     // ---- origin grids (host/origin_grid.cpp, csrc/pt_grid.h): camera rays, shadow rays of point lights.  They depend on the
     // scene description only, not on the KD-tree: built on a thread of their own BESIDE the KD build (both are seconds of
@@ -1506,6 +1478,14 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         const char* e = getenv("PT_WF_ALLWIDE");
         return e && *e ? atoi(e) != 0 : false;
     }();
+    // k_wf_trace / k_wf_shadow hand the rays their walker's slack does not cover to k_wf_trace_exact / k_og_shadow_offgrid
+    // (csrc/pt_integrator.h, slop model).  PT_WF_EXACT=0 is for A/B measurements of what that costs only: the capped walk.
+    // 1: k_wf_trace lists them when it fetches them, k_wf_trace_exact runs behind it (beside the shade pass over the queue);
+    // 2: k_wf_shade lists them when it makes the rays, k_wf_trace_exact runs beside k_wf_trace.
+    static const uint32_t wf_exact = [] {
+        const char* e = getenv("PT_WF_EXACT");
+        return (uint32_t)(e && *e ? std::min(2, std::max(0, atoi(e))) : 1);
+    }();
     static const uint32_t wf_defer = [] {   // k_wf_trace: age (loop iterations) at which a cast leaves a drained wavefront
         const char* e = getenv("PT_WF_DEFER");
         return (uint32_t)(e && *e ? atoi(e) : 16);
@@ -1583,7 +1563,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       w.contrib.try_ensure((size_t)cap * 16u * lights) && w.rng[0].try_ensure((size_t)cap * 32u) &&
                       (!(multi_chunk && wf_overlap) || w.rng[1].try_ensure((size_t)cap * 32u)) &&
                       (!alpha || w.draws.try_ensure((size_t)cap * 4u)) &&   // RNG draw index of the alpha walk
-                      (!use_light_grids || w.offgrid.try_ensure((size_t)cap * 4u)) &&   // surfaces left to the KD-tree
+                      w.offgrid.try_ensure((size_t)cap * 4u) &&   // shadow jobs left to k_og_shadow_offgrid (long normals; rays the wavefront walker does not take)
+                      w.exact[0].try_ensure((size_t)cap * 8u) && w.exact[1].try_ensure((size_t)cap * 8u) &&   // casts left to k_wf_trace_exact: queue index + hit word
+                                                                                                        // (wf_exact_words), one list per bounce parity
                       // casts left to k_wf_trace_wide: at most one per lane in flight when the queue runs dry
                       // (4 B the queue index + 20 B a hit + 4 B the progress of the walk: wf_list_* in pt_wavefront.h)
                       (!(use_cam_grid && use_light_grids) || w.block_mask.try_ensure((size_t)blocks64 * 4u + 4u + tm.n_local)) &&
@@ -1594,7 +1576,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 if (multi_chunk) s.wf_cap_ok = cap;   // (a frame that fits in one chunk says nothing about larger ones)
                 break;
             }
-            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1], &w.draws, &w.offgrid, &w.deferred, &w.block_mask})
+            for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1], &w.draws, &w.offgrid, &w.deferred, &w.exact[0], &w.exact[1], &w.block_mask})
                 b->release();
             if (cap <= (1u << 20))
                 fail(PT_ERR_DEVICE, "out of device memory: the path queues need %zu bytes for %u work items",
@@ -1614,9 +1596,19 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_shadow, hipEventDisableTiming));
         }
         if (wf_overlap && !w.side_wide) {
-            HIP_CHECK(hipStreamCreateWithFlags(&w.side_wide, hipStreamNonBlocking));
+            // (high priority: their few workgroups - the long casts of the drain, the casts the wavefront walker does not take -
+            // run beside the shade pass over the queue, whose thousands of short workgroups would otherwise take every slot
+            // that comes free before them; PT_WF_SIDE_PRIORITY=0: default priority)
+            int prio_lo = 0, prio_hi = 0;
+            HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            const char* pe = getenv("PT_WF_SIDE_PRIORITY");
+            const int prio = (pe && *pe && atoi(pe) == 0) ? prio_lo : prio_hi;
+            HIP_CHECK(hipStreamCreateWithPriority(&w.side_wide, hipStreamNonBlocking, prio));
+            HIP_CHECK(hipStreamCreateWithPriority(&w.side_exact, hipStreamNonBlocking, prio));
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_trace, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_wide, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&w.ev_exact, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&w.ev_exact_go, hipEventDisableTiming));
         }
     }
     uint32_t blocks = tm.n_local_tiles * (o.tile_w * o.tile_h / 256u);
@@ -1662,7 +1654,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                      o.tile_h, o.sample_batch, (uint64_t)d_rgb8, (uint64_t)accum, (uint64_t)d_tiles, cap, batch,
                      (uint64_t)s.staging_buf.p, (uint64_t)w.queue[0].p, (uint64_t)w.queue[1].p, (uint64_t)w.hits.p,
                      (uint64_t)w.shadow.p, (uint64_t)w.contrib.p, (uint64_t)w.ctr.p, (uint64_t)w.rng[0].p, (uint64_t)w.rng[1].p,
-                     (uint64_t)w.draws.p, (uint64_t)w.offgrid.p, (uint64_t)w.deferred.p, (uint64_t)s.trace_blocks,
+                     (uint64_t)w.draws.p, (uint64_t)w.offgrid.p, (uint64_t)w.deferred.p, (uint64_t)w.exact[0].p, (uint64_t)w.exact[1].p, (uint64_t)s.trace_blocks,
                      (uint64_t)s.shadow_blocks, (uint64_t)tm.n_local, (uint64_t)tm.n_local_tiles, (uint64_t)w.block_mask.p};
         auto hit = s.graphs.find(graph_key);
         if (hit != s.graphs.end()) {
@@ -1746,6 +1738,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     return (uint32_t)(e && *e ? atoi(e) != 0 : 0);
                 }();
                 W.use_entry = wf_entry;
+                W.exact_handover = wf_exact ? 1u : 0u;   // (per bounce below: 1 k_wf_trace lists, 2 k_wf_shade listed)
+                W.exact_shade_lists = wf_exact == 2u ? 1u : 0u;
 
                 W.refill_min = std::max(1u, std::min(64u, wf_refill));
                 W.walk_steps = wf_walk ? wf_walk : 20u;
@@ -1819,6 +1813,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
 #define PT_SHADE_ARGS                                                                                                         \
     s.dev, W, d_tiles, (const float4*)q_in, shade_hits, (const uint4*)rng_planes, (const uint32_t*)pipe.draws.p, \
         q_out, (float4*)pipe.shadow.p, (float4*)pipe.contrib.p, (float*)s.staging_buf.p, shade_list,                 \
+        (const uint32_t*)pipe.exact[b & 1].p, (const uint4*)pipe.hits.p, (uint32_t*)pipe.exact[(b + 1) & 1].p,      \
         (grid_mode >= 2 ? block_empty : (const uint32_t*)nullptr), wctr, gctr
 #define PT_LAUNCH_SHADE(A, C, P, G)                                                                                    \
     hipLaunchKernelGGL((k_wf_shade<A, C, P, G>), dim3(shade_grid), dim3(WF_SHADE_THREADS), 0, st_main, PT_SHADE_ARGS)
@@ -1867,12 +1862,68 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                                 split_shade = false;
                                 W.list_cap = cap;
                                 W.split_deferred = 0u;
+                            }
+                            // The casts the wavefront walker does not take (slack_is_capped): one lane each on the grown-box walker.
+                            // Bounces >= 1: k_wf_shade listed them when it made the rays, so the launch goes out BEFORE the
+                            // persistent kernel, on a stream of its own, and runs beside it (its few hundred workgroups take
+                            // their slots first; the persistent grid's last workgroups start as those free up).  Camera rays of
+                            // the KD-tree pipeline: k_wf_trace lists them, the launch follows it.
+                            W.exact_handover = (wf_exact && !allwide) ? (prim ? 1u : wf_exact) : 0u;
+                            // (beside the persistent kernel: a SMALL grid - every workgroup of it takes a slot from k_wf_trace for as
+                            // long as it runs, and 2048 workgroups held most of the chip for milliseconds: closed room 185 -> 199 ms.
+                            // PT_WF_EXACT_BLOCKS: workgroups per 8 CUs)
+                            static const uint32_t exact_blocks = [] {
+                                const char* e = getenv("PT_WF_EXACT_BLOCKS");
+                                return (uint32_t)(e && *e ? atoi(e) : 4);
+                            }();
+                            auto launch_exact = [&](hipStream_t st_exact) {
+                                const dim3 eg(W.exact_handover == 2u ? std::max(1u, (uint32_t)s.n_cu * exact_blocks / 8u) : (uint32_t)s.n_cu * 16u);
+#define PT_LAUNCH_EXACT(C, A, P)                                                                                               \
+    hipLaunchKernelGGL((k_wf_trace_exact<C, A, P>), eg, dim3(WF_EXACT_THREADS), 0, st_exact, s.dev, W, d_tiles, (const float4*)q_in, \
+                       (uint4*)pipe.hits.p, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (uint32_t*)pipe.exact[b & 1].p, \
+                       (const WfCounters*)wctr, gctr)
+                                if (prim) {
+                                    if (alpha && counting) PT_LAUNCH_EXACT(true, true, true);
+                                    else if (alpha) PT_LAUNCH_EXACT(false, true, true);
+                                    else if (counting) PT_LAUNCH_EXACT(true, false, true);
+                                    else PT_LAUNCH_EXACT(false, false, true);
+                                } else {
+                                    if (alpha && counting) PT_LAUNCH_EXACT(true, true, false);
+                                    else if (alpha) PT_LAUNCH_EXACT(false, true, false);
+                                    else if (counting) PT_LAUNCH_EXACT(true, false, false);
+                                    else PT_LAUNCH_EXACT(false, false, false);
+                                }
+#undef PT_LAUNCH_EXACT
+                                HIP_CHECK(hipGetLastError());
+                            };
+                            if (W.exact_handover == 2u) {
+                                if (split_shade) {
+                                    HIP_CHECK(hipEventRecord(pipe.ev_exact_go, st_main));   // (the shade pass that listed them is done)
+                                    HIP_CHECK(hipStreamWaitEvent(pipe.side_exact, pipe.ev_exact_go, 0));
+                                    launch_exact(pipe.side_exact);
+                                    HIP_CHECK(hipEventRecord(pipe.ev_exact, pipe.side_exact));
+                                } else {
+                                    launch_exact(st_main);
+                                }
+                            }
+                            if (allwide) {
                                 hipLaunchKernelGGL(k_wf_list_identity, dim3((uint32_t)s.n_cu * 8u), dim3(256), 0, st_main,
                                                    (uint32_t*)pipe.deferred.p, cap, wctr, b);
                                 HIP_CHECK(hipGetLastError());
                             } else {
                                 PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
-                                              (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (uint32_t*)pipe.deferred.p, wctr, gctr);
+                                              (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (uint32_t*)pipe.deferred.p,
+                                              (uint32_t*)pipe.exact[b & 1].p, wctr, gctr);
+                            }
+                            if (W.exact_handover == 1u) {   // behind k_wf_trace: beside the shade pass over the queue if that is split off
+                                if (split_shade) {
+                                    HIP_CHECK(hipEventRecord(pipe.ev_exact_go, st_main));
+                                    HIP_CHECK(hipStreamWaitEvent(pipe.side_exact, pipe.ev_exact_go, 0));
+                                    launch_exact(pipe.side_exact);
+                                    HIP_CHECK(hipEventRecord(pipe.ev_exact, pipe.side_exact));
+                                } else {
+                                    launch_exact(st_main);
+                                }
                             }
                             if (W.defer_age) {   // the casts the drained wavefronts handed over (pt_wavefront.h)
                                 // split shade pass: on a stream of its own, underneath k_wf_shade's pass over the queue
@@ -1895,8 +1946,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                                 else PT_LAUNCH_WIDE(false, false);
 #undef PT_LAUNCH_WIDE
                                 HIP_CHECK(hipGetLastError());
-                                if (split_shade) HIP_CHECK(hipEventRecord(pipe.ev_wide, st_wide));
                             }
+                            if (split_shade) HIP_CHECK(hipEventRecord(pipe.ev_wide, pipe.side_wide));
                         }
                         stage_end();
                         ++launches;
@@ -1932,6 +1983,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                         // ... and the casts that were with k_wf_trace_wide meanwhile: the hand-over list (at most one entry per
                         // lane of the trace grid; usually a few thousand - a launch that finds an empty list returns)
                         HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_wide, 0));
+                        if (W.exact_handover) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_exact, 0));
                         shade_hits = (const uint4*)((const uint32_t*)pipe.deferred.p + W.list_cap);
                         shade_list = (const uint32_t*)pipe.deferred.p;
                         shade_grid = std::min(shade_grid, (uint32_t)s.n_cu);
@@ -1955,6 +2007,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
 #define PT_OGS_ARGS                                                                                                    \
     s.dev, Ws, (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, \
         (uint32_t*)pipe.offgrid.p, wctr, gctr
+#define PT_OGSH_ARGS                                                                                                   \
+    s.dev, Ws, (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, \
+        (uint32_t*)pipe.offgrid.p, order, wctr, gctr
                     if (grid_mode != 0) {
                         // what is left in the shadow queue: surfaces with a normal too long for the grids' margin
                         // (normally none: the launch finds an empty queue and returns)
@@ -1967,10 +2022,37 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             return (uint32_t)(e && *e ? atoi(e) : 16);
                         }();
                         const dim3 g((uint32_t)s.n_cu * std::max(1u, ogs_blocks));
+                        // EXPERIMENT (PT_SHADOW_SORT=<end bit>, PT_SHADOW_SORT_BEGIN=<begin bit>): the records in the order of their
+                        // light-grid cells.  The host reads the record count here (a synchronisation per bounce).
+                        static const int sort_end = [] { const char* e = getenv("PT_SHADOW_SORT"); return e && *e ? atoi(e) : 0; }();
+                        static const int sort_begin = [] { const char* e = getenv("PT_SHADOW_SORT_BEGIN"); return e && *e ? atoi(e) : 0; }();
+                        const uint32_t* order = nullptr;
+                        if (sort_end > 0 && !capture.st) {
+                            HIP_CHECK(hipStreamSynchronize(st_main));
+                            uint32_t n_sh = 0;
+                            HIP_CHECK(hipMemcpy(&n_sh, &wctr[b].shadow_count, 4, hipMemcpyDeviceToHost));
+                            if (n_sh > 100000u) {
+                                pt_scene::WfPipe& wp = s.pipe;
+                                for (int k = 0; k < 2; ++k) {
+                                    wp.sort_keys[k].ensure((size_t)cap * 4u);
+                                    wp.sort_vals[k].ensure((size_t)cap * 4u);
+                                }
+                                const size_t tb = pt_sort_temp_bytes(n_sh, sort_begin, sort_end);
+                                wp.sort_temp.ensure(tb + 256);
+                                hipLaunchKernelGGL(k_og_shadow_keys, dim3((uint32_t)s.n_cu * 8u), dim3(256), 0, st_shadow, s.dev, Ws,
+                                                   (const float4*)pipe.shadow.p, (uint32_t*)wp.sort_keys[0].p, (uint32_t*)wp.sort_vals[0].p,
+                                                   (const WfCounters*)wctr);
+                                HIP_CHECK(hipGetLastError());
+                                HIP_CHECK(pt_sort_pairs(wp.sort_temp.p, tb, (const uint32_t*)wp.sort_keys[0].p, (uint32_t*)wp.sort_keys[1].p,
+                                                        (const uint32_t*)wp.sort_vals[0].p, (uint32_t*)wp.sort_vals[1].p, n_sh, sort_begin, sort_end,
+                                                        st_shadow));
+                                order = (const uint32_t*)wp.sort_vals[1].p;
+                            }
+                        }
 #define PT_LAUNCH_OGSH(A, C)                                                                                   \
     do {                                                                                                       \
-        if (s.ortho_light_grids) hipLaunchKernelGGL((k_og_shadow<A, C, true>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS); \
-        else hipLaunchKernelGGL((k_og_shadow<A, C, false>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);          \
+        if (s.ortho_light_grids) hipLaunchKernelGGL((k_og_shadow<A, C, true>), g, dim3(256), 0, st_shadow, PT_OGSH_ARGS); \
+        else hipLaunchKernelGGL((k_og_shadow<A, C, false>), g, dim3(256), 0, st_shadow, PT_OGSH_ARGS);          \
     } while (0)
                         if (alpha && counting) PT_LAUNCH_OGSH(true, true);
                         else if (alpha) PT_LAUNCH_OGSH(true, false);
@@ -1982,8 +2064,14 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                         else hipLaunchKernelGGL((k_og_shadow_offgrid<false, true>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, PT_OGS_ARGS);
                         HIP_CHECK(hipGetLastError());
                     } else {
-                        PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, s.dev, Ws, (const float4*)pipe.shadow.p,
-                                     (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, wctr, gctr);
+                        PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, s.dev, Ws, (float4*)pipe.shadow.p,
+                                     (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, (uint32_t*)pipe.offgrid.p, wctr, gctr);
+                        // ... and the jobs it set aside: a shadow ray the wavefront walker does not take (normally a few per mille)
+                        if (Ws.exact_handover) {
+                            if (counting) hipLaunchKernelGGL((k_og_shadow_offgrid<true, true>), dim3((uint32_t)s.n_cu * 4u), dim3(256), 0, st_shadow, PT_OGS_ARGS);
+                            else hipLaunchKernelGGL((k_og_shadow_offgrid<false, true>), dim3((uint32_t)s.n_cu * 4u), dim3(256), 0, st_shadow, PT_OGS_ARGS);
+                            HIP_CHECK(hipGetLastError());
+                        }
                     }
                     stage_end();
                     stage_stream = st_main;
@@ -1991,6 +2079,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     else if (st_shadow_main != st_main) HIP_CHECK(hipEventRecord(pipe.ev_shadow, st_main));   // (keeps the waits below valid)
                     st_shadow = st_shadow_main;
 #undef PT_OGS_ARGS
+#undef PT_OGSH_ARGS
 #undef PT_LAUNCH_ACP
 #undef PT_LAUNCH_AC
 #undef PT_LAUNCH_SHADE_P
@@ -2102,7 +2191,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
                                  c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes,
                                  c.trace_nodes, c.trace_tris, c.shadow_skipped, c.bounce0_hits, c.bounce0_shadow_rays,
-                                 c.bounce0_tris, c.grid_tris, c.bounce0_cam_tris, c.deferred_casts};
+                                 c.bounce0_tris, c.grid_tris, c.bounce0_cam_tris, c.deferred_casts, c.exact_casts};
         if (getenv("PT_DEBUG_HIST")) {   // casts of k_wf_trace by length (bins of 64 node visits; bin 0 not counted)
             fprintf(stderr, "[pt] cast length histogram (x64 nodes):");
             for (int b = 1; b < 16; ++b) fprintf(stderr, " %llu", c.cast_hist[b]);
@@ -2497,7 +2586,8 @@ int pt_trace_rays(const pt_scene* scene, const float* rays, uint64_t n, pt_hit* 
 // The same through the WAVEFRONT integrator's own cast kernel (k_wf_trace: persistent lanes, resumable walk with the
 // LDS stack and tree top, optional hand-over to k_wf_trace_wide) - the kernel the rays of bounces >= 1 of every frame
 // go through.  mode bit 0: entry lists (trav_enter, the primitive each ray starts on in start_prims); bit 1: every
-// cast is handed to k_wf_trace_wide as early as possible.
+// cast is handed to k_wf_trace_wide as early as possible; bit 2: WITHOUT the hand-over of the rays the walker's slack does
+// not cover to k_wf_trace_exact (study switch: the capped walk of round 3).
 int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint32_t* start_prims, uint64_t n, uint32_t mode, pt_hit* out) {
     return guarded([&] {
         if (!scene || !rays || !out) fail(PT_ERR_INVALID, "pt_trace_rays_wavefront: null argument");
@@ -2540,9 +2630,17 @@ int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint
         W.defer_age = (mode & 2u) ? 1u : 0u;
         W.list_cap = blocks * WF_THREADS;
         W.use_entry = mode & 1u;
+        W.exact_handover = (mode & 4u) ? 0u : 1u;   // (as in every frame: the rays the walker's slack does not cover go to k_wf_trace_exact)
+        Staged<uint32_t> d_exact(nullptr, (size_t)cap * 2);
         hipLaunchKernelGGL((k_wf_trace<false, false, false>), dim3(blocks), dim3(WF_THREADS), 0, 0, scene->dev, W, (const uint32_t*)nullptr,
-                           d_q.d, d_hits.d, (const uint4*)nullptr, (uint32_t*)nullptr, d_def.d, d_ctr.d, (DevCounters*)nullptr);
+                           d_q.d, d_hits.d, (const uint4*)nullptr, (uint32_t*)nullptr, d_def.d, d_exact.d, d_ctr.d, (DevCounters*)nullptr);
         HIP_CHECK(hipGetLastError());
+        if (W.exact_handover) {
+            hipLaunchKernelGGL((k_wf_trace_exact<false, false, false>), dim3((uint32_t)std::max(1, n_cu) * 16u), dim3(WF_EXACT_THREADS), 0, 0, scene->dev, W,
+                               (const uint32_t*)nullptr, (const float4*)d_q.d, d_hits.d, (const uint4*)nullptr, (uint32_t*)nullptr, d_exact.d,
+                               (const WfCounters*)d_ctr.d, (DevCounters*)nullptr);
+            HIP_CHECK(hipGetLastError());
+        }
         if (W.defer_age) {
             hipLaunchKernelGGL((k_wf_trace_wide<false, false>), dim3((uint32_t)std::max(1, n_cu) * 4u * (WF_WIDE_LANES / 16u > 0u ? WF_WIDE_LANES / 16u : 1u)), dim3(WF_THREADS), 0, 0, scene->dev, W,
                                (const uint32_t*)nullptr, (const float4*)d_q.d, d_hits.d, (const uint4*)nullptr, (uint32_t*)nullptr,

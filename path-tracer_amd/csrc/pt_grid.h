@@ -105,7 +105,7 @@ PT_D bool og_next_hit(const DevScene& S, const DevGrid& G, uint32_t cell, f3 o, 
         og_test_closest<COUNT>(o, d, pp[0], pp[1], pp[2], t_prev, ord_prev, best, lc);
     }
     // kdtree-ray's box test (scene_slab): a ray it rejects has no hits at all
-    if (best.pid != 0xffffffffu && !hit_passes_slab(S, best.pid, o, d)) best.pid = 0xffffffffu;
+    if (best.pid != 0xffffffffu && !hit_passes_slab(S, o, d)) best.pid = 0xffffffffu;
     return best.pid != 0xffffffffu;
 }
 
@@ -148,7 +148,7 @@ PT_D uint32_t og_blocker(const DevScene& S, const DevGrid& G, uint32_t cell, f3 
 template <bool COUNT, bool RANGED>
 PT_D bool og_blocked(const DevScene& S, const DevGrid& G, uint32_t cell, f3 so, f3 sd, f3 pos, float ldist, LocalCtr& lc) {
     const uint32_t pid = og_blocker<COUNT, RANGED>(S, G, cell, so, sd, pos, ldist, lc);
-    return pid != 0xffffffffu && hit_passes_slab(S, pid, so, sd);
+    return pid != 0xffffffffu && hit_passes_slab(S, so, sd);
 }
 
 

@@ -82,6 +82,12 @@ struct WfParams {
     uint32_t split_deferred;   // k_wf_trace marks the casts it hands over WF_HIT_PENDING, k_wf_trace_wide stores THEIR hits by
                                // list position in the list's own plane, and k_wf_shade's pass over the queue leaves them to a
                                // second launch over that list
+    uint32_t exact_handover;   // k_wf_trace / k_wf_shadow: a cast whose ray would need more slack than PT_SLACK_MAX (slack_is_capped,
+                               // pt_integrator.h) is not walked here but left to k_wf_trace_exact / k_og_shadow_offgrid.  1: k_wf_trace
+                               // lists it when it fetches it (camera rays of the KD-tree pipeline, test hook); 2: k_wf_shade listed it
+                               // when it wrote the ray (bounces >= 1: k_wf_trace_exact then runs BESIDE k_wf_trace, not behind it),
+                               // k_wf_trace only leaves it alone.  0: the capped walk of round 3 (A/B measurements only)
+    uint32_t exact_shade_lists;   // k_wf_shade lists the survivors whose new ray k_wf_trace will not take (exact_handover 2 at the next bounce)
 };
 
 // A path queue of capacity `cap` records is two planes of 32 bytes per record (the casts read the first only, the misses
@@ -109,6 +115,7 @@ struct WfCounters {  // one set per bounce level, zeroed once per chunk
     uint32_t shadow_work[WF_CURSORS * WF_CURSOR_STRIDE];
     uint32_t offgrid_count;  // shadow records k_og_shadow left to k_og_shadow_offgrid (pt_grid_kernels.h)
     uint32_t deferred_count; // casts k_wf_trace left to k_wf_trace_wide in its drain phase
+    uint32_t exact_count;    // casts k_wf_trace left to k_wf_trace_exact when it fetched them (slack_is_capped)
 };
 
 #define WF_FLAG_TERMINATED 1u
@@ -673,7 +680,7 @@ PT_D void wf_store_alpha_state(uint32_t* list, uint32_t cap, uint32_t slot, floa
     list[(size_t)cap * 9 + slot] = draw;
     const uint4 r = pack_hit(kept, have_kept);
     list[(size_t)cap * 10 + slot] = r.x;
-    if (have_kept) ((uint4*)(list + (size_t)cap * 11))[slot] = make_uint4(r.y, r.z, r.w, kept.pid & PT_PRIM_EDGE);
+    if (have_kept) ((uint4*)(list + (size_t)cap * 11))[slot] = make_uint4(r.y, r.z, r.w, 0u);
 }
 PT_D bool wf_load_alpha_state(const uint32_t* list, uint32_t cap, uint32_t slot, float& t_prev, uint32_t& ord_prev, uint32_t& draw,
                               RawHit& kept) {
@@ -684,24 +691,27 @@ PT_D bool wf_load_alpha_state(const uint32_t* list, uint32_t cap, uint32_t slot,
     if (x == 0xffffffffu) return false;
     const uint4 k = ((const uint4*)(list + (size_t)cap * 11))[slot];
     unpack_hit(make_uint4(x, k.x, k.y, k.z), kept);
-    kept.pid |= k.w & PT_PRIM_EDGE;
     return true;
 }
-// (a carried hit keeps its PT_PRIM_EDGE mark - the hit word has no room for it - in the spare word of the second plane)
 PT_D void wf_store_carry(uint32_t* list, uint32_t list_cap, uint32_t slot, const RawHit& h) {
     const bool hit = h.pid != 0xffffffffu;
     const uint4 r = pack_hit(h, hit);
     list[list_cap + slot] = r.x;
-    if (hit) ((uint4*)(list + (size_t)list_cap * 2))[slot] = make_uint4(r.y, r.z, r.w, h.pid & PT_PRIM_EDGE);
+    if (hit) ((uint4*)(list + (size_t)list_cap * 2))[slot] = make_uint4(r.y, r.z, r.w, 0u);
 }
 PT_D bool wf_load_carry(const uint32_t* list, uint32_t list_cap, uint32_t slot, RawHit& h) {
     const uint32_t x = list[list_cap + slot];
     if (x == 0xffffffffu) return false;
     const uint4 k = ((const uint4*)(list + (size_t)list_cap * 2))[slot];
     unpack_hit(make_uint4(x, k.x, k.y, k.z), h);
-    h.pid |= k.w & PT_PRIM_EDGE;
     return true;
 }
+
+// The exact list (k_wf_trace -> k_wf_trace_exact), `cap` entries (a queue entry is listed at most once): the queue index
+// (4 B), then - split shade pass - the hit's WORD by list position (4 B); the rest of the hit (key, u, v) goes to the chunk's
+// own hit plane at the queue index, whose word stays WF_HIT_PENDING while the pass of k_wf_shade over the queue is running.
+PT_D uint32_t* wf_exact_words(uint32_t* list, uint32_t cap) { return list + cap; }
+PT_D const uint32_t* wf_exact_words(const uint32_t* list, uint32_t cap) { return list + cap; }
 
 PT_D float wf_rng_float(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0f); }  // rng.gen::<f32>()
 
@@ -842,6 +852,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                                                          float4* __restrict__ queue, uint4* __restrict__ hits,
                                                          const uint4* __restrict__ rng_planes,
                                                          uint32_t* __restrict__ draws, uint32_t* __restrict__ deferred,
+                                                         uint32_t* __restrict__ exact_list,
                                                          WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
     __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
@@ -876,7 +887,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
     auto complete = [&]() {
         lstate = WF_LANE_WALK;
         bool hit = best.pid != 0xffffffffu;
-        if (hit && !hit_passes_slab(S, best.pid, T.o, T.d)) {   // kdtree-ray's box test: no hits at all
+        if (hit && !hit_passes_slab(S, T.o, T.d)) {   // kdtree-ray's box test: no hits at all
             hit = false;
             have_kept = false;
         }
@@ -945,7 +956,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
         bool need = !active && !exhausted;
         unsigned long long m_need = __ballot(need);
         if (m_need && ((uint32_t)__popcll(m_need) >= W.refill_min || !__any(active))) {
-            bool got;
+            bool got, handover = false;
             uint32_t w = wave_fetch(wf, cursor, n, need, got, exhausted);
             if (got) {
                 idx = w;
@@ -988,6 +999,22 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                 active = true;
                 // outside the image / misses the scene box: answered as "no hit" below
                 lstate = (!valid_item || !(PRIMARY ? trav_start(S, T, o, d, 0.f) : trav_enter(S, T, st, o, d, entry_word))) ? WF_LANE_DONE : WF_LANE_WALK;
+                // A ray that would need more slack than PT_SLACK_MAX is not walked by this walker at all (slop model,
+                // pt_integrator.h): it is listed for k_wf_trace_exact and the lane takes another entry at the next refill.
+                // (the reciprocals are trav_start's own: both sides of the switch-over see the same numbers)
+                handover = W.exact_handover && lstate == WF_LANE_WALK &&
+                           slack_is_capped(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+            }
+            if (wf_any(handover)) {   // (0.24 % of random directions)
+                uint32_t slot = 0u;
+                if (W.exact_handover == 1u) slot = wf_reserve(&ctr[W.bounce].exact_count, handover);   // (2: k_wf_shade listed it)
+                if (handover) {
+                    if (W.exact_handover == 1u) exact_list[slot] = idx;
+                    if (W.split_deferred) ((uint32_t*)hits)[idx] = WF_HIT_PENDING;
+                    if (COUNT) lc.segments--;   // counted by k_wf_trace_exact
+                    active = false;
+                    lstate = WF_LANE_IDLE;
+                }
             }
         }
         WF_STAMP(st_refill);
@@ -1344,7 +1371,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
                 if (live) {
                     if (winners) {
                         if (lane == (uint32_t)__ffsll((long long)winners) - 1u)
-                            wf_store_hit(hits, h_cap, h_idx, best, hit_passes_slab(S, best.pid, T.o, T.d));
+                            wf_store_hit(hits, h_cap, h_idx, best, hit_passes_slab(S, T.o, T.d));
                     } else if (part == 0u) {
                         wf_store_hit(hits, h_cap, h_idx, best, false);
                     }
@@ -1361,7 +1388,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
                 win.flags = __shfl(best.flags, src);
                 if (live) {
                     bool hit = winners != 0ull;
-                    if (hit && !hit_passes_slab(S, win.pid, T.o, T.d)) {   // kdtree-ray's box test: no hits at all
+                    if (hit && !hit_passes_slab(S, T.o, T.d)) {   // kdtree-ray's box test: no hits at all
                         hit = false;
                         have_kept = false;
                     }
@@ -1431,6 +1458,410 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
     }
 }
 
+// ---------------------------------------------------------------------------
+// The casts k_wf_trace did not take: rays that would need more slack than PT_SLACK_MAX in the wavefront walker (a direction
+// component below 8e-4; slop model in pt_integrator.h), on the fat-ray walker (FatRay, pt_integrator.h), whose candidate set
+// does not depend on the ray's direction.  WF_EXACT_LANES lanes per cast: the pending segments (node, interval) of a cast sit
+// on ONE stack in LDS; every round each lane takes one from the top - up to L nodes of the tree at once, their fetches in
+// flight together -, an interior node puts back the children the fat ray touches, a leaf is tested by the lane that took it.
+// The visiting order is free (the cast's hit is the minimum of a total order over all accepted hits), so nothing needs
+// sorting; a segment that starts beyond the group's best hit is dropped.  With one lane per cast (first form) a launch took
+// as long as its longest cast - ~1000 nodes one after the other: 2.1 ms for the 130 000 casts of config 3's bounce 1.
+// The alpha walk (mod.rs:188-205) as in k_wf_trace's complete(), group-uniform as in k_wf_trace_wide.
+// PRIMARY: the camera rays of the KD-tree-only pipeline (entry = work item of the chunk).  W.split_deferred: the pass of
+// k_wf_shade over the queue is running meanwhile - the hit's word goes to the exact list's own plane (by list position), the
+// rest to the chunk's plane at the queue index, whose word stays WF_HIT_PENDING.
+// ---------------------------------------------------------------------------
+#ifndef WF_EXACT_LANES
+#define WF_EXACT_LANES 16u
+#endif
+#ifndef WF_EXACT_COOP
+#define WF_EXACT_COOP 0   // 1: the lane-cooperative form below; 0: one lane per cast with its stack in LDS (k_wf_trace_exact1)
+#endif
+#define WF_EXACT_SOFT 192u   // above this many pending segments a group goes depth first, one segment per round ...
+#define WF_EXACT_CAP 272u    // ... which adds at most one entry per level of the tree (PT_KD_STACK = 64) before it shrinks
+template <bool COUNT, bool ALPHA, bool PRIMARY>
+__global__ __launch_bounds__(256) void k_wf_trace_exact_coop(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
+                                                        const float4* __restrict__ queue, uint4* __restrict__ hits,
+                                                        const uint4* __restrict__ rng_planes, uint32_t* __restrict__ draws,
+                                                        uint32_t* __restrict__ exact_list, const WfCounters* __restrict__ ctr,
+                                                        DevCounters* __restrict__ gctr) {
+    constexpr uint32_t L = WF_EXACT_LANES, GROUPS = 256u / L;
+    static_assert(WF_EXACT_SOFT + PT_KD_STACK + L <= WF_EXACT_CAP, "stack of the exact walker");
+    __shared__ uint32_t st_node[GROUPS][WF_EXACT_CAP];
+    __shared__ float st_t0[GROUPS][WF_EXACT_CAP], st_t1[GROUPS][WF_EXACT_CAP];
+    const uint32_t n = ctr[W.bounce].exact_count;
+    if (n == 0u) return;
+    const uint32_t group = threadIdx.x / L, part = threadIdx.x & (L - 1u), lane = threadIdx.x & 63u;
+    const unsigned long long group_mask = ((1ull << L) - 1ull) << (lane & ~(L - 1u));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};
+    uint32_t n_alpha_draws = 0;
+    const uint32_t passes = (n + gridDim.x * GROUPS - 1u) / (gridDim.x * GROUPS);   // (whole wavefronts stay in the loops together)
+    for (uint32_t r = 0; r < passes; ++r) {
+        const uint32_t e = (r * gridDim.x + blockIdx.x) * GROUPS + group;
+        const bool have = e < n;
+        const uint32_t idx = have ? exact_list[e] : 0u;
+        f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
+        uint32_t item = idx, draw = 2u;   // (PRIMARY: the pixel jitter)
+        if (have) {
+            if (PRIMARY) {
+                const uint2 sc = *(const uint2*)(rng_planes + idx);   // jittered screen position (k_wf_rng); valid: k_wf_trace checked
+                primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
+            } else {
+                const float4* q = wf_ray_rec(queue, idx);
+                const float4 q0 = q[0], q1 = q[1];
+                o = mk3(q0.x, q0.y, q0.z);
+                d = mk3(q0.w, q1.x, q1.y);
+                item = __float_as_uint(q1.z);
+                draw = __float_as_uint(q1.w) & 0xffffu;
+            }
+        }
+        if (COUNT && have && part == 0u) lc.segments++;
+        const float dlen = mag3(d);
+        const float key_scale = dlen < 1.0f ? dlen : 1.0f;   // key >= t * min(1, |d|)
+        FatRay F;
+        float r0 = 0.f, r1 = 0.f;
+        const bool in_scene = have && F.init(S, o, d, 0.f, r0, r1);
+        float t_prev = -INFINITY;
+        uint32_t ord_prev = 0u;
+        RawHit kept, win;
+        kept.pid = win.pid = 0xffffffffu;
+        bool have_kept = false, hit = false, live = have;
+        do {   // one turn per entry of the sorted hit list the alpha walk looks at (opaque scenes: one)
+            RawHit best;
+            best.key = INFINITY;
+            best.ord = 0xffffffffu;
+            best.pid = 0xffffffffu;
+            best.u = best.v = 0.f;
+            best.flags = 0u;
+            uint32_t count = (live && in_scene) ? 1u : 0u;   // pending segments of the group's cast (the same in its L lanes)
+            if (count && part == 0u) {
+                st_node[group][0] = 0u;
+                st_t0[group][0] = r0;
+                st_t1[group][0] = r1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            while (wf_any(count != 0u)) {
+                float gkey = best.key;   // the group's best distance so far: what every lane culls against
+#pragma unroll
+                for (uint32_t m = L / 2u; m >= 1u; m >>= 1) {
+                    const float k2 = __shfl_xor(gkey, (int)m);
+                    gkey = k2 < gkey ? k2 : gkey;
+                }
+                const uint32_t pops = count > WF_EXACT_SOFT ? 1u : (count < L ? count : L);
+                const bool take = part < pops;
+                uint32_t node = 0u;
+                float t0 = 0.f, t1 = 0.f;
+                if (take) {
+                    node = st_node[group][count - 1u - part];
+                    t0 = st_t0[group][count - 1u - part];
+                    t1 = st_t1[group][count - 1u - part];
+                }
+                count -= pops;
+                __builtin_amdgcn_wave_barrier();
+                // (the segment's hits have keys >= t0 * min(1, |d|): beyond the best one it holds nothing of interest)
+                uint32_t n_push = 0u, c_node[2] = {0u, 0u};
+                float c_t0[2] = {0.f, 0.f}, c_t1[2] = {0.f, 0.f};
+                if (take && !(t0 * key_scale > gkey + PT_EXIT_ABS)) {
+                    const uint2 nd = S.kd_nodes[node];
+                    if (COUNT) lc.nodes++;
+                    const uint32_t axis = nd.y & 3u;
+                    if (axis != 3u) {
+                        const uint32_t lo = nd.y >> 2, hi = lo + 1u;
+                        float b0, b1, a0, a1;
+                        bool vb, va;
+                        F.children(axis, __uint_as_float(nd.x), t0, t1, vb, b0, b1, va, a0, a1);
+                        const bool below_first = b0 <= a0;   // the nearer child goes on top
+                        if (vb && va) {
+                            c_node[0] = below_first ? hi : lo;
+                            c_t0[0] = below_first ? a0 : b0;
+                            c_t1[0] = below_first ? a1 : b1;
+                            c_node[1] = below_first ? lo : hi;
+                            c_t0[1] = below_first ? b0 : a0;
+                            c_t1[1] = below_first ? b1 : a1;
+                            n_push = 2u;
+                        } else if (vb || va) {
+                            c_node[0] = vb ? lo : hi;
+                            c_t0[0] = vb ? b0 : a0;
+                            c_t1[0] = vb ? b1 : a1;
+                            n_push = 1u;
+                        }
+                    } else {
+                        const uint32_t n_refs = nd.y >> 2;
+                        const float4* lp = S.leaf_prims + (size_t)nd.x * 3;
+                        for (uint32_t i = 0; i < n_refs; ++i) {
+                            float4 q0, q1, q2;
+                            load_prim_record(lp + 3 * i, q0, q1, q2);
+                            og_test_closest<COUNT>(o, d, q0, q1, q2, t_prev, ord_prev, best, lc);
+                        }
+                    }
+                }
+                // put the children back: exclusive prefix of n_push over the group's lanes
+                const unsigned long long m1 = __ballot(n_push >= 1u) & group_mask, m2 = __ballot(n_push == 2u) & group_mask;
+                const uint32_t off = (uint32_t)__popcll(m1 & below) + (uint32_t)__popcll(m2 & below);
+                if (n_push >= 1u) {
+                    st_node[group][count + off] = c_node[0];
+                    st_t0[group][count + off] = c_t0[0];
+                    st_t1[group][count + off] = c_t1[0];
+                }
+                if (n_push == 2u) {
+                    st_node[group][count + off + 1u] = c_node[1];
+                    st_t0[group][count + off + 1u] = c_t0[1];
+                    st_t1[group][count + off + 1u] = c_t1[1];
+                }
+                count += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // the group's minimum of (key, ord): every lane takes the winner's record
+            float kmin = best.key;
+            uint32_t omin = best.ord;
+#pragma unroll
+            for (uint32_t m = L / 2u; m >= 1u; m >>= 1) {
+                const float k2 = __shfl_xor(kmin, (int)m);
+                const uint32_t o2 = __shfl_xor(omin, (int)m);
+                if (key_less(k2, o2, kmin, omin)) {
+                    kmin = k2;
+                    omin = o2;
+                }
+            }
+            const bool found = best.pid != 0xffffffffu && best.key == kmin && best.ord == omin;
+            const unsigned long long winners = __ballot(found) & group_mask;
+            const int src = winners ? __ffsll((long long)winners) - 1 : (int)lane;
+            win.key = __shfl(best.key, src);
+            win.ord = __shfl(best.ord, src);
+            win.pid = __shfl(best.pid, src);
+            win.u = __shfl(best.u, src);
+            win.v = __shfl(best.v, src);
+            win.flags = __shfl(best.flags, src);
+            bool again = false;
+            if (live) {
+                hit = winners != 0ull;
+                if (hit && !hit_passes_slab(S, o, d)) {   // kdtree-ray's box test: no hits at all
+                    hit = false;
+                    have_kept = false;
+                }
+                if (ALPHA && hit) {
+                    const float opacity = hit_opacity(S, o, d, win);
+                    if (COUNT && part == 0u) lc.shaded++;
+                    bool stop = opacity >= 1.f;
+                    if (!stop && opacity > 0.001f) {
+                        WfRng fb;
+                        fb.block = 0xffffffffu;
+                        stop = wf_rng_draw(fb, W, tile_offsets, rng_planes, item, draw++) < opacity;
+                        if (COUNT && part == 0u) n_alpha_draws++;
+                    }
+                    if (!stop) {   // skipped: remember it, the group looks for the next entry of the sorted list
+                        kept = win;
+                        have_kept = true;
+                        t_prev = win.key;
+                        ord_prev = win.ord;
+                        if (COUNT && part == 0u) lc.restarts++;
+                        again = true;   // (from the origin again: these are the rare rays, and "behind t_prev" needs no slack argument
+                                        //  this way - the acceptance rule of the leaf tests is the only filter)
+                    }
+                }
+                if (!again) {
+                    if (ALPHA && !hit && have_kept) {   // every hit skipped: the last one is shaded
+                        win = kept;
+                        hit = true;
+                    }
+                    if (part == 0u) {
+                        if (W.split_deferred) {
+                            const uint4 rec = pack_hit(win, hit);
+                            wf_exact_words(exact_list, W.cap)[e] = rec.x;
+                            if (hit) ((uint4*)((uint32_t*)hits + W.cap))[idx] = make_uint4(rec.y, rec.z, rec.w, 0u);
+                        } else {
+                            wf_store_hit(hits, W.cap, idx, win, hit);
+                        }
+                        if (ALPHA) draws[idx] = draw;
+                    }
+                    live = false;
+                }
+            }
+            if (!wf_any(again)) break;
+        } while (true);
+    }
+    if (COUNT) {
+        atomicAdd(&gctr->segments, (unsigned long long)lc.segments);
+        atomicAdd(&gctr->exact_casts, (unsigned long long)lc.segments);
+        atomicAdd(&gctr->nodes_visited, (unsigned long long)lc.nodes);
+        atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->trace_nodes, (unsigned long long)lc.nodes);
+        atomicAdd(&gctr->trace_tris, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
+        if (ALPHA) atomicAdd(&gctr->shaded_hits, (unsigned long long)lc.shaded);
+        if (ALPHA) atomicAdd(&gctr->rng_draws, (unsigned long long)n_alpha_draws);
+    }
+}
+
+// One lane per cast: 64 walks per wavefront in flight (the cooperative form above has four, and most of a walk is the descent
+// to its first leaf, one segment wide).  The stack of pending segments - (node, interval), 12 bytes - in LDS, [entry][thread]
+// like k_wf_trace's, the rare deep part in scratch: with the whole stack in scratch (first form) every push and pop of a
+// wavefront whose lanes are at different depths was 64 separate cache lines.
+#define WF_EXACT_LDS_STACK 16
+#define WF_EXACT_THREADS 128
+template <bool COUNT, bool ALPHA, bool PRIMARY>
+__global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S, WfParams W, const uint32_t* __restrict__ tile_offsets,
+                                                        const float4* __restrict__ queue, uint4* __restrict__ hits,
+                                                        const uint4* __restrict__ rng_planes, uint32_t* __restrict__ draws,
+                                                        uint32_t* __restrict__ exact_list, const WfCounters* __restrict__ ctr,
+                                                        DevCounters* __restrict__ gctr) {
+    __shared__ uint32_t s_node[WF_EXACT_LDS_STACK][WF_EXACT_THREADS];
+    __shared__ float s_t0[WF_EXACT_LDS_STACK][WF_EXACT_THREADS], s_t1[WF_EXACT_LDS_STACK][WF_EXACT_THREADS];
+    uint32_t ov_node[PT_KD_STACK - WF_EXACT_LDS_STACK];
+    float ov_t0[PT_KD_STACK - WF_EXACT_LDS_STACK], ov_t1[PT_KD_STACK - WF_EXACT_LDS_STACK];
+    const uint32_t n = ctr[W.bounce].exact_count, tid = threadIdx.x;
+    LocalCtr lc = {0, 0, 0, 0, 0, 0};
+    uint32_t n_alpha_draws = 0;
+    for (uint32_t e = blockIdx.x * WF_EXACT_THREADS + tid; e < n; e += gridDim.x * WF_EXACT_THREADS) {
+        const uint32_t idx = exact_list[e];
+        f3 o, d;
+        uint32_t item = idx, draw = 2u;   // (PRIMARY: the pixel jitter)
+        if (PRIMARY) {
+            const uint2 sc = *(const uint2*)(rng_planes + idx);   // jittered screen position (k_wf_rng); valid: k_wf_trace checked
+            primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
+        } else {
+            const float4* q = wf_ray_rec(queue, idx);
+            const float4 q0 = q[0], q1 = q[1];
+            o = mk3(q0.x, q0.y, q0.z);
+            d = mk3(q0.w, q1.x, q1.y);
+            item = __float_as_uint(q1.z);
+            draw = __float_as_uint(q1.w) & 0xffffu;
+        }
+        if (COUNT) lc.segments++;
+        const float dlen = mag3(d);
+        const float key_scale = dlen < 1.0f ? dlen : 1.0f;   // key >= t * min(1, |d|)
+        FatRay F;
+        float r0 = 0.f, r1 = 0.f;
+        const bool in_scene = F.init(S, o, d, 0.f, r0, r1);
+        RawHit best, kept;
+        bool have_kept = false, hit = false;
+        float t_prev = -INFINITY;
+        uint32_t ord_prev = 0u;
+        while (true) {   // one turn per entry of the sorted hit list the alpha walk looks at (opaque scenes: one)
+            best.key = INFINITY;
+            best.ord = 0xffffffffu;
+            best.pid = 0xffffffffu;
+            if (in_scene) {
+                int sp = 0;
+                uint32_t node = 0u;
+                float t0 = r0, t1 = r1;
+                while (true) {
+                    const uint2 nd = S.kd_nodes[node];
+                    if (COUNT) lc.nodes++;
+                    const uint32_t axis = nd.y & 3u;
+                    bool descend = false;
+                    if (axis != 3u) {
+                        const uint32_t lo = nd.y >> 2, hi = lo + 1u;
+                        float b0, b1, a0, a1;
+                        bool vb, va;
+                        F.children(axis, __uint_as_float(nd.x), t0, t1, vb, b0, b1, va, a0, a1);
+                        const bool below_first = b0 <= a0;
+                        if (vb && va) {   // the farther child waits
+                            const uint32_t fn = below_first ? hi : lo;
+                            const float f0 = below_first ? a0 : b0, f1 = below_first ? a1 : b1;
+                            if (sp < WF_EXACT_LDS_STACK) {
+                                s_node[sp][tid] = fn;
+                                s_t0[sp][tid] = f0;
+                                s_t1[sp][tid] = f1;
+                            } else {
+                                ov_node[sp - WF_EXACT_LDS_STACK] = fn;
+                                ov_t0[sp - WF_EXACT_LDS_STACK] = f0;
+                                ov_t1[sp - WF_EXACT_LDS_STACK] = f1;
+                            }
+                            ++sp;
+                            node = below_first ? lo : hi;
+                            t0 = below_first ? b0 : a0;
+                            t1 = below_first ? b1 : a1;
+                            descend = true;
+                        } else if (vb || va) {
+                            node = vb ? lo : hi;
+                            t0 = vb ? b0 : a0;
+                            t1 = vb ? b1 : a1;
+                            descend = true;
+                        }
+                    } else {
+                        const uint32_t n_refs = nd.y >> 2;
+                        const float4* lp = S.leaf_prims + (size_t)nd.x * 3;
+                        for (uint32_t i = 0; i < n_refs; ++i) {
+                            float4 q0, q1, q2;
+                            load_prim_record(lp + 3 * i, q0, q1, q2);
+                            og_test_closest<COUNT>(o, d, q0, q1, q2, t_prev, ord_prev, best, lc);
+                        }
+                    }
+                    if (descend) continue;
+                    bool more = false;
+                    while (sp > 0) {
+                        --sp;
+                        if (sp < WF_EXACT_LDS_STACK) {
+                            node = s_node[sp][tid];
+                            t0 = s_t0[sp][tid];
+                            t1 = s_t1[sp][tid];
+                        } else {
+                            node = ov_node[sp - WF_EXACT_LDS_STACK];
+                            t0 = ov_t0[sp - WF_EXACT_LDS_STACK];
+                            t1 = ov_t1[sp - WF_EXACT_LDS_STACK];
+                        }
+                        // (the segment's hits have keys >= t0 * min(1, |d|): beyond the best one it holds nothing of interest)
+                        if (!(t0 * key_scale > best.key + PT_EXIT_ABS)) {
+                            more = true;
+                            break;
+                        }
+                    }
+                    if (!more) break;
+                }
+            }
+            hit = best.pid != 0xffffffffu;
+            if (hit && !hit_passes_slab(S, o, d)) {   // kdtree-ray's box test: no hits at all
+                hit = false;
+                have_kept = false;
+            }
+            if (!ALPHA || !hit) break;
+            const float opacity = hit_opacity(S, o, d, best);
+            if (COUNT) lc.shaded++;
+            bool stop = opacity >= 1.f;
+            if (!stop && opacity > 0.001f) {
+                WfRng fb;
+                fb.block = 0xffffffffu;
+                stop = wf_rng_draw(fb, W, tile_offsets, rng_planes, item, draw++) < opacity;
+                if (COUNT) n_alpha_draws++;
+            }
+            if (stop) break;
+            kept = best;   // skipped: remember it, look for the next entry of the sorted list (from the origin again: these are
+            have_kept = true;   // the rare rays, and "behind t_prev" needs no slack argument this way)
+            t_prev = best.key;
+            ord_prev = best.ord;
+            if (COUNT) lc.restarts++;
+        }
+        if (ALPHA && !hit && have_kept) {   // every hit skipped: the last one is shaded
+            best = kept;
+            hit = true;
+        }
+        if (W.split_deferred) {
+            const uint4 rec = pack_hit(best, hit);
+            wf_exact_words(exact_list, W.cap)[e] = rec.x;
+            if (hit) ((uint4*)((uint32_t*)hits + W.cap))[idx] = make_uint4(rec.y, rec.z, rec.w, 0u);
+        } else {
+            wf_store_hit(hits, W.cap, idx, best, hit);
+        }
+        if (ALPHA) draws[idx] = draw;
+    }
+    if (COUNT) {
+        atomicAdd(&gctr->segments, (unsigned long long)lc.segments);
+        atomicAdd(&gctr->exact_casts, (unsigned long long)lc.segments);
+        atomicAdd(&gctr->nodes_visited, (unsigned long long)lc.nodes);
+        atomicAdd(&gctr->tris_tested, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->trace_nodes, (unsigned long long)lc.nodes);
+        atomicAdd(&gctr->trace_tris, (unsigned long long)lc.tris);
+        atomicAdd(&gctr->restarts, (unsigned long long)lc.restarts);
+        if (ALPHA) atomicAdd(&gctr->shaded_hits, (unsigned long long)lc.shaded);
+        if (ALPHA) atomicAdd(&gctr->rng_draws, (unsigned long long)n_alpha_draws);
+    }
+}
+
 // A light whose term (thr ⊙ eval_direct) is exactly (0,0,0) - it lies below the shading horizon and the
 // surface is not emissive - adds 0 ⊙ radiance to the colour (mod.rs:255-261), i.e. nothing, whatever
 // the shadow ray finds, as long as the radiance is finite: colour finite and, for a point light, the
@@ -1483,18 +1914,39 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
                                                   float4* __restrict__ queue_out, float4* __restrict__ shadow_q,
                                                   float4* __restrict__ contrib, float* __restrict__ staging,
                                                   const uint32_t* __restrict__ index_list,
+                                                  const uint32_t* __restrict__ exact_list, const uint4* __restrict__ chunk_hits,
+                                                  uint32_t* __restrict__ exact_next,
                                                   const uint32_t* __restrict__ block_empty,
                                                   WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     // index_list (bounces >= 1): null - the whole queue, entries marked WF_HIT_PENDING left out; else the entries to shade:
     // the hand-over list of k_wf_trace, whose casts k_wf_trace_wide has finished by now - `hits` is then that list's
     // own plane (W.list_cap records, by list position).  The pass over the queue runs WHILE k_wf_trace_wide walks
-    // those few long casts (16 lanes each, a launch bound by its longest cast).
+    // those few long casts (16 lanes each, a launch bound by its longest cast).  Behind that list, in the same launch, the
+    // exact list (k_wf_trace_exact, pt_wavefront.h wf_exact_words): word by list position, the rest of the hit in the chunk's
+    // own plane (chunk_hits) at the queue index.  exact_next: the exact list of the NEXT bounce - a survivor whose new ray the
+    // wavefront walker will not take (slack_is_capped) is listed here, where the ray is made, so that k_wf_trace_exact can
+    // walk it while k_wf_trace is busy with the rest of the queue.
     constexpr int GRID = GRIDX & 3;
     constexpr bool DIRL = GRIDX >= 4;
     static_assert(GRIDX != 4, "DIRL needs a grid mode");
     uint4* rng_planes_out = const_cast<uint4*>(rng_planes);   // GRID == 3 writes plane 1 (nobody reads it before bounce 1)
     static_assert(GRID < 2 || PRIMARY, "the camera grid serves bounce 0");
-    const uint32_t n = PRIMARY ? W.n_items : index_list ? ctr[W.bounce].deferred_count : ctr[W.bounce].queue_count;
+    const bool list_pass = !PRIMARY && index_list != nullptr;
+    const uint32_t n_def = list_pass ? ctr[W.bounce].deferred_count : 0u;
+    const uint32_t n = PRIMARY ? W.n_items : list_pass ? n_def + (exact_list ? ctr[W.bounce].exact_count : 0u) : ctr[W.bounce].queue_count;
+    // entry e of this launch: its queue record, the word of its hit, the hit
+    auto entry_index = [&](uint32_t e) -> uint32_t { return !list_pass ? e : e < n_def ? index_list[e] : exact_list[e - n_def]; };
+    auto entry_word = [&](uint32_t e) -> uint32_t {
+        return (!list_pass || e < n_def) ? wf_hit_word(hits, e) : wf_exact_words(exact_list, W.cap)[e - n_def];
+    };
+    auto entry_hit = [&](uint32_t e, uint32_t i, RawHit& h) -> bool {
+        if (!list_pass) return wf_load_hit(hits, W.cap, e, h);
+        if (e < n_def) return wf_load_hit(hits, W.list_cap, e, h);
+        const uint32_t x = wf_exact_words(exact_list, W.cap)[e - n_def];
+        if (x == 0xffffffffu) return false;
+        const uint4 k = ((const uint4*)((const uint32_t*)chunk_hits + W.cap))[i];
+        return unpack_hit(make_uint4(x, k.x, k.y, k.z), h);
+    };
     uint32_t n_draws = 0, n_new = 0, n_moot = 0, n_hits = 0, n_cam_tris = 0;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};   // (GRID: casts made here)
     __shared__ uint32_t sh_cnt[2][WF_SHADE_THREADS / 64];
@@ -1506,9 +1958,8 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
     // the instruction count and the 52 active lanes per instruction unchanged, profiles/r02_experiments.txt item 13.)
     // One workgroup-wide step: thread t shades queue entry i (live = it has one).  Every thread of the workgroup
     // calls this together: the compaction at the end has barriers.
-    const uint32_t hit_cap = (!PRIMARY && index_list) ? W.list_cap : W.cap;
-    auto shade_one = [&](const uint32_t e, bool live) {   // e: position in the queue / in index_list
-    const uint32_t i = (!PRIMARY && index_list && live) ? index_list[e] : e;
+    auto shade_one = [&](const uint32_t e, bool live) {   // e: position in the queue / in the lists
+    const uint32_t i = (list_pass && live) ? entry_index(e) : e;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), color = mk3(0, 0, 0);
     uint32_t item = i, draw = 0, out_slot = 0;
     RawHit h;
@@ -1601,7 +2052,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
         item = __float_as_uint(q1.z);
         draw = ALPHA ? draws[i] : (__float_as_uint(q1.w) & 0xffffu);
         out_slot = __float_as_uint(q2.w);
-        hit = wf_load_hit(hits, hit_cap, e, h);
+        hit = entry_hit(e, i, h);
         if (out_slot == 0xffffffffu) live = false;  // (records of items outside the image; none since bounce 0 is fused)
     }
     const uint32_t bounce = PRIMARY ? 0u : W.bounce, bounces = W.P.bounces;   // (PRIMARY: no Russian roulette code at all)
@@ -1728,6 +2179,13 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
     if (W.sort_octants & 1u) next_idx = sh_base[0] + sh_oct_off[oct][wave] + oct_rank;
     __syncthreads();  // sh_cnt / sh_base are rewritten by the next step
     if (GRID == 3 && survive) rng_planes_out[(size_t)W.cap + item] = later_words;   // draws 4-7 of the path
+    if (W.exact_shade_lists) {   // (wave-uniform; 0.24 % of random directions)
+        const bool listed = survive && slack_is_capped(__builtin_amdgcn_rcpf(next_d.x), __builtin_amdgcn_rcpf(next_d.y), __builtin_amdgcn_rcpf(next_d.z));
+        if (wf_any(listed)) {
+            const uint32_t slot = wf_reserve(&ctr[bounce + 1].exact_count, listed);
+            if (listed) exact_next[slot] = next_idx;
+        }
+    }
     if (survive) {
         float4* qr = wf_ray_rec(queue_out, next_idx);
         float4* qp = wf_path_rec(queue_out, W.cap, next_idx);
@@ -1772,7 +2230,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
         const bool cull = PRIMARY && GRID >= 2 && !COUNT && block_empty != nullptr && block_empty[W.n_mask_blocks] != 0u;
         for (uint32_t base = blockIdx.x * WF_SHADE_THREADS; base < n; base += gridDim.x * WF_SHADE_THREADS) {
             const uint32_t e = base + threadIdx.x;
-            bool live = e < n && (PRIMARY || wf_hit_word(hits, e) != WF_HIT_PENDING);
+            bool live = e < n && (PRIMARY || entry_word(e) != WF_HIT_PENDING);
             if (cull) {   // a step whose four wavefronts are all empty skips the compaction's barriers as well
                 const uint32_t g0 = (W.item_base + base) >> 6;
                 bool step_empty = true;
@@ -1801,10 +2259,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
         while (true) {
             while (have < WF_SHADE_THREADS && base < n) {
                 const uint32_t e = base + threadIdx.x;
-                const uint32_t i = (index_list && e < n) ? index_list[e] : e;   // (queue record; the hit is stored at e)
+                const uint32_t i = e < n ? entry_index(e) : e;   // (queue record; the hit is stored by e)
                 base += gridDim.x * WF_SHADE_THREADS;
                 bool is_hit = false;
-                const uint32_t word = e < n ? wf_hit_word(hits, e) : WF_HIT_PENDING;
+                const uint32_t word = e < n ? entry_word(e) : WF_HIT_PENDING;
                 if (word != WF_HIT_PENDING) {
                     is_hit = word != 0xffffffffu;
                     if (!is_hit) {
@@ -1845,7 +2303,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
                 __shared__ uint32_t agg_sorted[WF_SHADE_THREADS];
                 uint32_t key = 8u, rank = 0u;
                 if (threadIdx.x < take) {
-                    const uint32_t prim = wf_hit_word(hits, mine) & 0x0fffffffu;
+                    const uint32_t prim = entry_word(mine) & 0x0fffffffu;
                     key = __float_as_uint(S.prim_attr[(size_t)prim * 4 + 3].w) & 7u;
                 }
 #pragma unroll
@@ -1898,9 +2356,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
 // k_wf_trace; a job is one shaded surface, its lights are cast one after the other.
 // ---------------------------------------------------------------------------
 template <bool ALPHA, bool COUNT>
-__global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES : WF_MIN_WAVES) void k_wf_shadow(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
+__global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES : WF_MIN_WAVES) void k_wf_shadow(DevScene S, WfParams W, float4* __restrict__ shadow_q,
                                                           const float4* __restrict__ contrib,
                                                           float4* __restrict__ queue_next, float* __restrict__ staging,
+                                                          uint32_t* __restrict__ offgrid,
                                                           WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
     __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
@@ -1922,7 +2381,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
     best.key = INFINITY;
     best.ord = 0xffffffffu;
     best.pid = 0xffffffffu;
-    bool active = false, exhausted = false, need_begin = false;
+    bool active = false, exhausted = false, need_begin = false, handed = false;
     uint32_t lstate = WF_LANE_IDLE;
     uint32_t mailbox = 0xffffffffu;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
@@ -1964,6 +2423,12 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
             }
             f3 so = pos + gn * 0.00001f;
             f3 sd = -1.f * direction;
+            // a shadow ray that would need more slack than PT_SLACK_MAX is not walked here (slop model, pt_integrator.h): the
+            // job goes on - from this light, with the colour so far - in k_og_shadow_offgrid, on the exact scalar walker
+            if (W.exact_handover && slack_is_capped(__builtin_amdgcn_rcpf(sd.x), __builtin_amdgcn_rcpf(sd.y), __builtin_amdgcn_rcpf(sd.z))) {
+                handed = true;
+                return false;
+            }
             if (COUNT) lc.shadow_rays++;
             blocked = false;
             t_prev = -INFINITY;
@@ -1999,7 +2464,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
         if (ALPHA) {
             // best = next entry of the sorted list: attenuate, then look for the following one
             bool more = best.pid != 0xffffffffu;
-            if (more && !hit_passes_slab(S, best.pid, T.o, T.d)) more = false;   // kdtree-ray's box test
+            if (more && !hit_passes_slab(S, T.o, T.d)) more = false;   // kdtree-ray's box test
             if (more) {
                 float opacity = 0.f;
                 if (point) {
@@ -2063,7 +2528,18 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
         }
         if (active && need_begin) {  // the ONE place a light's shadow cast starts
             need_begin = false;
-            if (!begin_light()) retire();
+            if (!begin_light()) {
+                if (handed) {   // (rare: one atomic per job is fine)
+                    handed = false;
+                    float4* sq = shadow_q + (size_t)idx * 4;
+                    sq[2] = make_float4(color.x, color.y, color.z, __uint_as_float(next_idx));
+                    sq[3] = make_float4(__uint_as_float(out_slot), __uint_as_float(sphere ? WF_FLAG_SPHERE : 0u), __uint_as_float(li), 0.f);
+                    offgrid[atomicAdd(&ctr[W.bounce].offgrid_count, 1u)] = idx;
+                    active = false;
+                } else {
+                    retire();
+                }
+            }
         }
         if (!__any(active)) {
             if (__all(exhausted)) break;
@@ -2083,8 +2559,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
                 // every opacity is exactly 1: any hit inside the light's range blocks it
                 const float4* lp = S.leaf_prims + (size_t)T.leaf.x * 3;
                 uint32_t np = T.leaf.y >> 2;
-                uint32_t blocker = 0u;
-                for (uint32_t i = 0; i < np && !blocked; ++i) {
+                        for (uint32_t i = 0; i < np && !blocked; ++i) {
                     float4 q0, q1, q2;
                     load_prim_record(lp + 3 * i, q0, q1, q2);
                     uint32_t pid = __float_as_uint(q0.w);
@@ -2097,7 +2572,6 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
                             continue;
                         if (point && mag3((T.o + T.d * t) - pos) > ldist) continue;
                         blocked = true;
-                        blocker = pid;
                     } else {
                         float t[2], key[2];
                         bool ex[2];
@@ -2106,12 +2580,11 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
                             if (!(key[k] == key[k])) continue;
                             if (point && mag3((T.o + T.d * t[k]) - pos) > ldist) continue;
                             blocked = true;
-                            blocker = pid;
                         }
                     }
                 }
                 // kdtree-ray's box test: a ray the scene box rejects has no hits at all
-                const bool rejected = blocked && !hit_passes_slab(S, blocker, T.o, T.d);
+                const bool rejected = blocked && !hit_passes_slab(S, T.o, T.d);
                 if (rejected) blocked = false;
                 lstate = (blocked || rejected || !trav_pop(T, st, limit)) ? WF_LANE_DONE : WF_LANE_WALK;
             } else {

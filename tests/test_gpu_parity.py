@@ -189,7 +189,6 @@ def test_seventh_golden_on_the_other_integrator_paths(pta, gpu_scene_cache, flag
     misses in the reference, oracle: kdtree_ray_slab): the KD-tree path and the megakernel apply it as well."""
     import hashlib
     g = gpu_scene_cache("white_furnace_direct")
-    assert g.info().n_edge_prims == 88       # the triangles within reach of two faces of the scene's box (108 in all)
     rgb, _ = g.render(pta.Profile.make(800, 600, 16, 0), pta.Opts.make(flags=getattr(pta, flags)))
     assert hashlib.sha1(rgb.tobytes()).hexdigest() == REFERENCE_SHA1["white_furnace_direct"]
 
@@ -471,6 +470,89 @@ def test_walk_slack_grows_with_the_smallest_direction_component(pta, oracle):
     assert np.array_equal(bits(acc[px]), bits(o_acc[0]))
 
 
+def near_axis_rays(scene, n, seed):
+    """Rays the wavefront walker does not take (pt_integrator.h slack_is_capped: a direction component below 8e-4, some exactly
+    0) through points ON edges of the scene's triangles - where a hit just outside a triangle's cell is decided."""
+    rng = np.random.default_rng(seed)
+    d = scene.desc.contents
+    tris = np.ctypeslib.as_array(d.triangles, (int(d.n_triangles) * 24,)).reshape(-1, 3, 8)[:, :, :3]   # (callers: n_triangles > 0)
+    t = rng.integers(0, len(tris), n)
+    k = rng.integers(0, 3, n)
+    w = rng.random(n).astype(np.float32)
+    p = tris[t, k] * w[:, None] + tris[t, (k + 1) % 3] * (1 - w[:, None])           # on an edge (mesh neighbours share it)
+    axis = rng.integers(0, 3, n)
+    dirs = np.zeros((n, 3), np.float32)
+    small = (10.0 ** rng.uniform(-9.0, -3.1, (n, 3))).astype(np.float32) * rng.choice([-1.0, 1.0], (n, 3)).astype(np.float32)
+    small[rng.random((n, 3)) < 0.15] = 0.0                                           # exactly axis-parallel components
+    both = rng.random(n) < 0.5                                                       # one small component, or two
+    other = rng.normal(size=n).astype(np.float32)
+    for i in range(3):
+        dirs[:, i] = small[:, i]
+    idx = np.arange(n)
+    dirs[idx, axis] = rng.choice([-1.0, 1.0], n).astype(np.float32)
+    second = (axis + 1) % 3
+    dirs[idx[~both], second[~both]] = other[~both]                                   # (a generic second component)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True).astype(np.float32)
+    dist = rng.uniform(0.3, 6.0, n).astype(np.float32)
+    o = (p - dirs * dist[:, None]).astype(np.float32)
+    return np.concatenate([o, dirs], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", SCENES + ["generated"])
+def test_near_axis_rays_go_through_the_exact_walker(pta, oracle, scene_cache, gpu_scene_cache, name):
+    """Round 4: a ray with a direction component below 8e-4 would need more than the wavefront walker's largest slack
+    (PT_SLACK_MAX); k_wf_trace lists it for k_wf_trace_exact (grown-box walker) instead of walking it with a capped slack.
+    Such rays - through mesh edges, components down to 1e-9 and exactly 0 - on every cast implementation == brute force."""
+    if name == "generated":
+        scene = pta.HostScene.generate_ps5(60000, seed=11, flags=4)
+        g = pta.GpuScene(scene)
+    else:
+        scene, g = scene_cache(name), gpu_scene_cache(name)
+    if scene.n_triangles == 0:
+        pytest.skip("no triangles")
+    osc = oracle.OracleScene(scene.desc, oracle.PTO_BRUTE_FORCE)
+    rays = near_axis_rays(scene, 6000 if name != "generated" else 3000, seed=17)
+    o_hits, o_cnt = osc.trace_all(rays, 16)
+    g_hits, g_cnt = g.trace_all(rays, 16)          # the scalar walker with the per-interval-end slack (kd_traverse)
+    assert np.array_equal(g_cnt, o_cnt) and np.array_equal(g_hits["prim"], o_hits["prim"])
+    assert np.array_equal(bits(g_hits["dist"]), bits(o_hits["dist"]))
+    for mode in (0, 2):                             # k_wf_trace (+ k_wf_trace_wide): hands these to k_wf_trace_exact
+        w = g.trace_wavefront(rays, None, mode)
+        assert np.array_equal(w["prim"], o_hits["prim"][:, 0]), mode
+        for f in ("dist", "u", "v"):
+            assert np.array_equal(bits(w[f]), bits(o_hits[f][:, 0])), (mode, f)
+        assert np.array_equal(w["flags"], o_hits["flags"][:, 0]), mode
+
+
+def test_axis_aligned_camera_frames_agree_on_every_path(pta, oracle):
+    """A camera that looks exactly along -z into the closed room: the middle columns and rows of the image are camera rays
+    with a component of a few 1e-4 and less, their mirror-like bounces likewise.  The frame on the default pipeline, on the
+    KD-tree pipeline (camera rays through k_wf_trace<PRIMARY>, shadow rays through k_wf_shadow: both hand over) and on the
+    megakernel: the same bits; oracle rows; and the hand-over happened."""
+    for flags in (4, 5):
+        scene = pta.HostScene.generate_ps5(30000, seed=5, flags=flags)
+        cam = scene.desc.contents.camera
+        m = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0.0, 2.0, 9.0, 1]
+        for i, v in enumerate(m):
+            cam.transform[i] = v
+        g = pta.GpuScene(scene)
+        prof = pta.Profile.make(321, 241, 6, 4, "FILMIC")
+        rgb, acc = g.render(prof)
+        for f in (pta.PT_FLAG_NO_GRIDS, pta.PT_FLAG_MEGAKERNEL):
+            rgb2, acc2 = g.render(prof, pta.Opts.make(flags=f))
+            assert np.array_equal(bits(acc), bits(acc2)) and np.array_equal(rgb, rgb2), (flags, f)
+        g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS))
+        c_grid = g.counters().as_dict()
+        g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS | pta.PT_FLAG_NO_GRIDS))
+        c_kd = g.counters().as_dict()
+        assert c_grid["exact_casts"] > 0 and c_kd["exact_casts"] > c_grid["exact_casts"]   # (KD-only: the camera rays too)
+        assert c_grid["segments"] == c_kd["segments"] and c_grid["shadow_rays"] == c_kd["shadow_rays"]
+        osc = oracle.OracleScene(scene.desc, oracle.PTO_BVH)
+        for row in (120, 121, 7):
+            o_rgb, o_acc, _ = osc.render(prof, row * prof.width, (row + 1) * prof.width)
+            assert np.array_equal(bits(acc[row * prof.width:(row + 1) * prof.width]), bits(o_acc)), (flags, row)
+
+
 def test_generated_scene_grid_and_kd_paths_agree(pta):
     for flags in (0, 1):   # opaque, translucent shells
         scene = pta.HostScene.generate_ps5(30000, seed=0, flags=flags)
@@ -540,7 +622,6 @@ def test_closed_room_generated_scene_is_bit_identical(pta, oracle, flags):
     the faces of the scene's bounding box, so this is also where kdtree-ray's box test (scene_slab) runs all the time."""
     scene = pta.HostScene.generate_ps5(12000, seed=0, flags=flags)
     g = pta.GpuScene(scene)
-    assert g.info().n_edge_prims > 0
     prof = pta.Profile.make(192, 108, 6, 8, "ACES")          # 8 bounces: Russian roulette from bounce 4 on
     o_rgb, o_acc, st = oracle.OracleScene(scene.desc, oracle.PTO_BVH).render(prof)
     assert st["numeric_errors"] == 0

@@ -122,3 +122,67 @@ def test_partial_render_is_the_viewer_feed(pta, oracle, scene_cache):
     # a 3-sample PROFILE uses another seed stride: different samples
     _, acc_other, _ = osc.render(pta.Profile.make(48, 32, 3, 2))
     assert not np.array_equal(acc_other.view(np.uint32), acc3.view(np.uint32))
+
+
+def _slab_study(pta, oracle, scene, profiles, rays=None):
+    """Oracle renders with the slab study on: (casts the slab test rejected although they had hits, of those the ones whose
+    origin is strictly inside the scene's box)."""
+    osc = oracle.OracleScene(scene.desc, oracle.PTO_BVH)
+    osc.slab_study_begin()
+    for prof in profiles:
+        osc.render(prof)
+    if rays is not None:
+        osc.trace_all(rays, 4)
+    return osc.slab_study()
+
+
+def test_slab_rejections_never_come_from_inside_the_box(pta, oracle, scene_cache):
+    """The product evaluates kdtree-ray's slab test (scene_slab) only for casts whose origin is NOT strictly inside the scene's
+    box (for an origin strictly inside, the f32 test cannot fail: csrc/pt_integrator.h hit_passes_slab); the oracle tests every
+    cast.  The two agree iff a cast the slab rejects although it has hits never starts strictly inside.  Counted here, on the
+    CPU, over the seven reference scenes (the seventh is the one whose golden pins two such rejections), the generated scenes
+    incl. the closed rooms whose walls lie in the faces of the box, rays aimed at the twelve edges of every box, and rays
+    that run IN a face plane of the box."""
+    rng = np.random.default_rng(23)
+    total_rejected = 0
+    cases = [(scene_cache(n), [pta.Profile.make(200, 150, 3, 3, "FILMIC")]) for n in list(GOLDEN_SHA1) + list(GOLDEN_SHA1_BOUNCES_0)]
+    # (the two camera rays of the seventh golden: pixels (677, 567) and (165, 577) of the 800 x 600 frame, samples 3 and 11)
+    cases.append((scene_cache("white_furnace_direct"), [pta.Profile.make(800, 600, 16, 0, "FILMIC")]))
+    for flags, tris in ((0, 3000), (4, 3000), (5, 4000), (7, 4000), (6, 12000)):
+        cases.append((pta.HostScene.generate_ps5(tris, seed=flags, flags=flags),
+                      [pta.Profile.make(97, 61, 3, 5, "ACES"), pta.Profile.make(64, 64, 2, 2, "FILMIC")]))
+    for scene, profs in cases:
+        d = scene.desc.contents
+        tri = np.zeros((0, 3, 3), np.float32)
+        if int(d.n_triangles):
+            tri = np.ctypeslib.as_array(d.triangles, (int(d.n_triangles) * 24,)).reshape(-1, 3, 8)[:, :, :3]
+        rays = None
+        if len(tri):   # rays through points within an ulp or two of the box's edges
+            lo, hi = tri.reshape(-1, 3).min(axis=0), tri.reshape(-1, 3).max(axis=0)
+            n = 4000
+            p = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+            a, b = rng.integers(0, 3, n), rng.integers(1, 3, n)
+            b = (a + b) % 3
+            idx = np.arange(n)
+            p[idx, a] = np.where(rng.random(n) < 0.5, lo[a], hi[a])
+            p[idx, b] = np.where(rng.random(n) < 0.5, lo[b], hi[b])
+            p = np.nextafter(p, p + rng.choice([-1.0, 0.0, 1.0], (n, 3)).astype(np.float32)).astype(np.float32)
+            o = (p + rng.normal(size=(n, 3)) * (hi - lo).max()).astype(np.float32)
+            dvec = (p - o)
+            dvec /= np.linalg.norm(dvec, axis=1, keepdims=True)
+            rays = np.concatenate([o, dvec.astype(np.float32)], axis=1).astype(np.float32)
+            # ... and rays that run IN a face plane of the box (origin coordinate exactly the face's, that direction component
+            # exactly 0 or subnormal): (bound - o) * inf is NaN, the crate's min / max keep the other bound's infinity - rejected
+            m = 2000
+            a = rng.integers(0, 3, m)
+            o2 = rng.uniform(lo - 1, hi + 1, (m, 3)).astype(np.float32)
+            d2 = rng.normal(size=(m, 3)).astype(np.float32)
+            d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+            j = np.arange(m)
+            o2[j, a] = np.where(rng.random(m) < 0.5, lo[a], hi[a])
+            d2[j, a] = rng.choice(np.array([0.0, -0.0, 1e-40, -1e-42], np.float32), m)
+            rays = np.concatenate([rays, np.concatenate([o2, d2], axis=1).astype(np.float32)])
+        rejected, from_inside = _slab_study(pta, oracle, scene, profs, rays)
+        assert from_inside == 0, (rejected, from_inside)
+        total_rejected += rejected
+    assert total_rejected > 0   # (the study saw what it is about: white_furnace_direct alone has such casts)
