@@ -38,7 +38,6 @@
 #include "pt_integrator.h"
 #include "pt_wavefront.h"
 #include "pt_grid_kernels.h"
-#include "pt_sort.h"
 #include "pt_grid_build.h"
 #include "pthost.h"
 
@@ -496,7 +495,7 @@ struct pt_scene {
     // The queues of the chunk of work items in flight.  The shadow casts of bounce b run on a side stream
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
-        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid, deferred, exact[2], block_mask, sort_keys[2], sort_vals[2], sort_temp;
+        DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid, deferred, exact[2], block_mask;
         hipStream_t side = nullptr, side_rng = nullptr, side_wide = nullptr, side_exact = nullptr;
         hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr, ev_trace = nullptr, ev_wide = nullptr,
                    ev_exact = nullptr, ev_exact_go = nullptr;
@@ -751,7 +750,11 @@ void prep_create(const pt_scene_desc& d, pt_prep& P, pt_scene* early = nullptr, 
         const double n_grids = 1.0 + d.n_lights;
         while (res > 512u && estimate(res) * n_grids > budget) res >>= 1;
         bool lights_fit = estimate(res) * n_grids <= budget;
-        const uint32_t light_res = res;
+        // (PT_OG_RES_LIGHT: experiments - the light grids at a resolution of their own)
+        const uint32_t light_res = [&] {
+            const char* e = getenv("PT_OG_RES_LIGHT");
+            return e && *e && atoi(e) >= 32 ? (uint32_t)atoi(e) : res;
+        }();
         if (!lights_fit) {   // the camera grid alone, at the resolution it is worth having
             res = pth_origin_grid_auto_resolution(n_prims);
             while (res > 512u && estimate(res) > budget) res >>= 1;
@@ -2007,9 +2010,6 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
 #define PT_OGS_ARGS                                                                                                    \
     s.dev, Ws, (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, \
         (uint32_t*)pipe.offgrid.p, wctr, gctr
-#define PT_OGSH_ARGS                                                                                                   \
-    s.dev, Ws, (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, \
-        (uint32_t*)pipe.offgrid.p, order, wctr, gctr
                     if (grid_mode != 0) {
                         // what is left in the shadow queue: surfaces with a normal too long for the grids' margin
                         // (normally none: the launch finds an empty queue and returns)
@@ -2022,37 +2022,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             return (uint32_t)(e && *e ? atoi(e) : 16);
                         }();
                         const dim3 g((uint32_t)s.n_cu * std::max(1u, ogs_blocks));
-                        // EXPERIMENT (PT_SHADOW_SORT=<end bit>, PT_SHADOW_SORT_BEGIN=<begin bit>): the records in the order of their
-                        // light-grid cells.  The host reads the record count here (a synchronisation per bounce).
-                        static const int sort_end = [] { const char* e = getenv("PT_SHADOW_SORT"); return e && *e ? atoi(e) : 0; }();
-                        static const int sort_begin = [] { const char* e = getenv("PT_SHADOW_SORT_BEGIN"); return e && *e ? atoi(e) : 0; }();
-                        const uint32_t* order = nullptr;
-                        if (sort_end > 0 && !capture.st) {
-                            HIP_CHECK(hipStreamSynchronize(st_main));
-                            uint32_t n_sh = 0;
-                            HIP_CHECK(hipMemcpy(&n_sh, &wctr[b].shadow_count, 4, hipMemcpyDeviceToHost));
-                            if (n_sh > 100000u) {
-                                pt_scene::WfPipe& wp = s.pipe;
-                                for (int k = 0; k < 2; ++k) {
-                                    wp.sort_keys[k].ensure((size_t)cap * 4u);
-                                    wp.sort_vals[k].ensure((size_t)cap * 4u);
-                                }
-                                const size_t tb = pt_sort_temp_bytes(n_sh, sort_begin, sort_end);
-                                wp.sort_temp.ensure(tb + 256);
-                                hipLaunchKernelGGL(k_og_shadow_keys, dim3((uint32_t)s.n_cu * 8u), dim3(256), 0, st_shadow, s.dev, Ws,
-                                                   (const float4*)pipe.shadow.p, (uint32_t*)wp.sort_keys[0].p, (uint32_t*)wp.sort_vals[0].p,
-                                                   (const WfCounters*)wctr);
-                                HIP_CHECK(hipGetLastError());
-                                HIP_CHECK(pt_sort_pairs(wp.sort_temp.p, tb, (const uint32_t*)wp.sort_keys[0].p, (uint32_t*)wp.sort_keys[1].p,
-                                                        (const uint32_t*)wp.sort_vals[0].p, (uint32_t*)wp.sort_vals[1].p, n_sh, sort_begin, sort_end,
-                                                        st_shadow));
-                                order = (const uint32_t*)wp.sort_vals[1].p;
-                            }
-                        }
 #define PT_LAUNCH_OGSH(A, C)                                                                                   \
     do {                                                                                                       \
-        if (s.ortho_light_grids) hipLaunchKernelGGL((k_og_shadow<A, C, true>), g, dim3(256), 0, st_shadow, PT_OGSH_ARGS); \
-        else hipLaunchKernelGGL((k_og_shadow<A, C, false>), g, dim3(256), 0, st_shadow, PT_OGSH_ARGS);          \
+        if (s.ortho_light_grids) hipLaunchKernelGGL((k_og_shadow<A, C, true>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS); \
+        else hipLaunchKernelGGL((k_og_shadow<A, C, false>), g, dim3(256), 0, st_shadow, PT_OGS_ARGS);          \
     } while (0)
                         if (alpha && counting) PT_LAUNCH_OGSH(true, true);
                         else if (alpha) PT_LAUNCH_OGSH(true, false);
@@ -2079,7 +2052,6 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     else if (st_shadow_main != st_main) HIP_CHECK(hipEventRecord(pipe.ev_shadow, st_main));   // (keeps the waits below valid)
                     st_shadow = st_shadow_main;
 #undef PT_OGS_ARGS
-#undef PT_OGSH_ARGS
 #undef PT_LAUNCH_ACP
 #undef PT_LAUNCH_AC
 #undef PT_LAUNCH_SHADE_P

@@ -83,35 +83,6 @@ PT_D void og_retire(f3 color, uint32_t next_idx, uint32_t out_slot, float4* __re
 }
 
 // ---------------------------------------------------------------------------
-// Order of the shadow queue by the cell of the FIRST light's grid its records look up (pt_gpu.hip sorts (key, index)):
-// key = cell >> shift_bits... the cell index itself is (face, row, column); records of neighbouring rows and columns share
-// list lines and triangles, so the key is the 8x8-cell block (face, row / 8, column / 8) and the position inside it.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_og_shadow_keys(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
-                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        const WfCounters* __restrict__ ctr) {
-    const uint32_t n = ctr[W.bounce].shadow_count;
-    const DevLight& L = S.lights[0];
-    const DevGrid& G = S.light_grids[0];
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const float4 s0 = shadow_q[(size_t)i * 4];
-        const f3 pos = mk3(s0.x, s0.y, s0.z);
-        uint32_t key;
-        if (L.kind == PT_LIGHT_POINT) {
-            uint32_t face, cu, cv;
-            og_cell_coords(G, pos - ld3(L.vec), face, cu, cv);
-            const uint32_t bits = 32u - (uint32_t)__builtin_clz(G.res - 1u) ;   // bits of a cell coordinate
-            // (face, block row, block column, row in block, column in block)
-            key = (((face << (bits - 3u)) | (cv >> 3)) << (bits - 3u) | (cu >> 3)) << 6 | (cv & 7u) << 3 | (cu & 7u);
-        } else {
-            key = og_cell_ortho(G, pos);   // (the normal bias moves a record by less than a cell)
-        }
-        keys[i] = key;
-        vals[i] = i;
-    }
-}
-
-// ---------------------------------------------------------------------------
 // shadow: get_light_info (mod.rs:281-333) for every light of every record of the shadow queue, all lights point
 // lights with a grid.  Same records in, same arithmetic per light, same order of the additions as k_wf_shadow.
 // A surface whose normal is too long for the grids' margin (|n| > 1.5: the shadow ray starts n * 1e-5 off the
@@ -125,15 +96,11 @@ template <bool ALPHA, bool COUNT, bool DIRL>
 __global__ __launch_bounds__(256, (!ALPHA && !COUNT && !DIRL) ? 8 : 1) void k_og_shadow(DevScene S, WfParams W, const float4* __restrict__ shadow_q,
                                                    const float4* __restrict__ contrib, float4* __restrict__ queue_next,
                                                    float* __restrict__ staging, uint32_t* __restrict__ offgrid,
-                                                   const uint32_t* __restrict__ order,
                                                    WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
-    // order: null - the queue as it is; else the records' indices in the order of their light-grid cells (k_og_shadow_keys + sort):
-    // consecutive lanes then read the same lists and triangles
     const uint32_t n = ctr[W.bounce].shadow_count;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     uint32_t n_skipped = 0;
-    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
-        const uint32_t idx = order ? order[j] : j;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += gridDim.x * 256u) {
         const float4* sq = shadow_q + (size_t)idx * 4;
         const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3];
         const f3 pos = mk3(s0.x, s0.y, s0.z), gn = mk3(s0.w, s1.x, s1.y);
