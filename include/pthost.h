@@ -40,7 +40,11 @@ const pt_scene_desc* pth_scene_desc(const pth_scene* s);
  *                normal map, metalness and roughness textures (one of them an
  *                albedo texture too), the core an emissive texture
  *                bit2: four walls and a ceiling close the scene into a room
- *                (no path escapes: the bounce loop runs to its end) */
+ *                (no path escapes: the bounce loop runs to its end)
+ *                bit3: the framing of the reference's PS5 render (readme/ps5_b5_s128.png:
+ *                38.8 % of its 8x8 pixel blocks are sky): a 12.94 x 12.94 ground seen
+ *                corner-on from above, the object a quarter of the frame, the light
+ *                behind it to the left (host/scene_gen.cpp has the fitted recipe) */
 int pth_scene_generate_ps5(uint64_t target_tris, uint64_t seed, uint32_t flags, pth_scene** out);
 
 /* Write a scene as ISF JSON (+ textures as PNG next to it). */

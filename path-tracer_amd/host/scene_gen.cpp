@@ -9,6 +9,20 @@
 // triangle count is a parameter; vertex jitter comes from the same PCG32
 // stream rand_core uses for seed expansion, so the scene is a pure function
 // of (target_tris, seed, flags).
+//
+// flags bit 3 (8): the REFERENCE'S FRAMING.  readme/ps5_b5_s128.png is all that is
+// known of the reference's config-3 workload: the console stands on a square ground
+// seen corner-on from above, 40.5 % of the image's pixels and 38.8 % of its 8x8 pixel
+// blocks are exactly black (sky), the ground fills the lower half, the object a
+// quarter of the frame, a long shadow runs to the right.  The recipe below - a
+// 12.94 x 12.94 ground instead of 24 x 24, the camera at azimuth 0.82 rad, 6.5 above
+// the ground, 8.6 from the axis (0.54 of the ground's far corner behind the object),
+// looking at (1, 1.87, 0), the light to the camera's left behind the object - was
+// fitted (tools/framing_fit.py: random search over the six numbers against the CPU
+// oracle's hit mask) to the image's fraction of empty blocks (0.387 vs 0.388) and to
+// its profile of empty blocks over 16 bands of rows and of columns (rms deviation
+// 0.03).  Without the flag: round 1-3's framing (camera in front of the object, low,
+// 52.5 % of the blocks empty).
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -134,7 +148,8 @@ void generate(uint64_t target, uint64_t seed, uint32_t flags, pth_scene& sc) {
     if (target > 200000000ull) fail(PT_ERR_INVALID, "target_tris too large");
     Pcg32 rng(seed);
     const double jitter = 2e-4;
-    const bool alpha = flags & 1u, textured = flags & 2u;
+    const bool alpha = flags & 1u, textured = flags & 2u, ref_framing = flags & 8u;
+    const double ground_half = ref_framing ? 6.47 : 12.0;   // half the ground's edge
     // procedural textures (flags bit 1): every texture kind of internal/material.rs:132-214 on the shells and the core
     auto add_texture = [&](uint32_t w, uint32_t h, uint32_t channels, const char* name,
                            const std::function<void(uint32_t, uint32_t, uint8_t*)>& texel) {
@@ -194,8 +209,8 @@ void generate(uint64_t target, uint64_t seed, uint32_t flags, pth_scene& sc) {
     uint64_t first;
     // 1. ground
     begin_mesh(sc, plain(0.55f, 0.55f, 0.58f, 0.5f, 0.f), first);
-    add_patch(sc, [](double s, double t) { return V3{-12 + 24 * s, 0.0, 12 - 24 * t}; }, g_ground, g_ground,
-              false, rng, 0.0, 24.0, false);
+    add_patch(sc, [=](double s, double t) { return V3{-ground_half + 2 * ground_half * s, 0.0, ground_half - 2 * ground_half * t}; },
+              g_ground, g_ground, false, rng, 0.0, 24.0, false);
     end_mesh(sc, first);
 
     // 2. glossy dark core (closed ellipsoid-like body)
@@ -288,7 +303,7 @@ void generate(uint64_t target, uint64_t seed, uint32_t flags, pth_scene& sc) {
     if (flags & 4u) {
         const uint32_t g = std::max(8u, g_ground / 4u);
         begin_mesh(sc, plain(0.95f, 0.93f, 0.90f, 0.5f, 0.f), first);
-        const double H = 10.0, E = 12.0;
+        const double H = 10.0, E = ground_half;
         // (patch normals point INTO the room: cross(ds, dt) with the parametrisations below)
         add_patch(sc, [=](double u, double v) { return V3{-E + 2 * E * u, H * v, -E}; }, g, g, false, rng, 0.0, 6.0, false);  // back  (+z)
         add_patch(sc, [=](double u, double v) { return V3{E - 2 * E * u, H * v, E}; }, g, g, false, rng, 0.0, 6.0, false);   // front (-z)
@@ -301,9 +316,9 @@ void generate(uint64_t target, uint64_t seed, uint32_t flags, pth_scene& sc) {
     // light, camera, background
     pt_light l{};
     l.kind = PT_LIGHT_POINT;
-    l.vec[0] = 3.5f;
-    l.vec[1] = 7.0f;
-    l.vec[2] = 6.0f;
+    l.vec[0] = ref_framing ? -5.5f : 3.5f;   // (reference framing: to the camera's left, behind the object - the shadow runs
+    l.vec[1] = ref_framing ? 7.5f : 7.0f;    //  to the right and towards the camera)
+    l.vec[2] = ref_framing ? 2.0f : 6.0f;
     l.color[0] = 3000.f;
     l.color[1] = 2900.f;
     l.color[2] = 2800.f;
@@ -311,6 +326,11 @@ void generate(uint64_t target, uint64_t seed, uint32_t flags, pth_scene& sc) {
     sc.lights.push_back(l);
 
     V3 P{0.6, 2.4, 9.0}, T{0.0, 1.9, 0.0};
+    if (ref_framing) {
+        const double az = 0.82, dist = 8.6;
+        P = V3{dist * std::sin(az) + 1.0, 6.5, dist * std::cos(az)};
+        T = V3{1.0, 1.87, 0.0};
+    }
     V3 f = norm(T - P);
     V3 right = norm(cross(f, V3{0, 1, 0}));
     V3 up = cross(right, f);

@@ -745,12 +745,24 @@ def _oracle_rows_equal(pta, oracle, scene, prof, gpu_acc, gpu_rgb, rows):
 
 @pytest.fixture(scope="module")
 def ps5_scene(pta):
-    scene = pta.HostScene.generate_ps5(500000, seed=0)
+    scene = pta.HostScene.generate_ps5(500000, seed=0, flags=8)   # the framing of the reference's render (bench.py's default)
     return scene, pta.GpuScene(scene)
 
 
+def test_config3_legacy_framing_rows(pta, oracle):
+    """The framing rounds 1-3 benchmarked (generator flags 0; bench.py still reports it as config.legacy_framing): oracle rows."""
+    scene = pta.HostScene.generate_ps5(500000, seed=0)
+    g = pta.GpuScene(scene)
+    prof = pta.Profile.make(1920, 1080, 128, 5, "FILMIC")
+    rgb, acc = g.render(prof)
+    _oracle_rows_equal(pta, oracle, scene, prof, acc, rgb, (0, 431, 1079))
+    blocks, empty = g.cull_stats()
+    assert abs(empty / blocks - 0.525) < 0.01   # (blocks: the 8x8 blocks of the 32x32 tiles that cover the image)
+
+
 def test_config3_full_size(pta, oracle, ps5_scene):
-    """BASELINE config 3: PS5 stand-in (499 392 triangles), 1920x1080, 128 spp, 5 bounces, FILMIC."""
+    """BASELINE config 3: PS5 stand-in (499 392 triangles) in the framing of the reference's own render, 1920x1080, 128 spp,
+    5 bounces, FILMIC."""
     scene, g = ps5_scene
     prof = pta.Profile.make(1920, 1080, 128, 5, "FILMIC")
     rgb, acc = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_COUNTERS))
@@ -761,8 +773,13 @@ def test_config3_full_size(pta, oracle, ps5_scene):
     assert c["segments"] - n <= c["shaded_hits"] <= c["segments"]    # a segment beyond the first needs a shaded hit
     assert c["rng_draws"] >= 2 * n and c["shadow_skipped"] <= c["shadow_rays"]
     assert np.isfinite(acc).all() and rgb.max() > 0
-    # (b) oracle rows: top, two through the model, bottom (ground plane)
-    _oracle_rows_equal(pta, oracle, scene, prof, acc, rgb, (0, 431, 540, 1079))
+    # (b) oracle rows: top (sky and the object's top), through the far corner of the ground, through the object and its
+    # shadow, bottom (ground)
+    _oracle_rows_equal(pta, oracle, scene, prof, acc, rgb, (30, 431, 540, 800, 1079))
+    # the framing: the share of 8x8 pixel blocks no camera ray can hit anything in - the reference's image has 38.8 % black blocks
+    g.render(prof)
+    blocks, empty = g.cull_stats()
+    assert abs(empty / blocks - 0.388) < 0.02   # (blocks: the 8x8 blocks of the 32x32 tiles that cover the image)
     # the drain phase of the persistent trace launches handed casts to k_wf_trace_wide (16 lanes per cast), and the
     # whole frame equals the megakernel's, which walks every cast with one lane from start to end
     assert c["deferred_casts"] > 0

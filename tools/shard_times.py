@@ -20,7 +20,7 @@ ap.add_argument('--width', type=int, default=1920)
 ap.add_argument('--height', type=int, default=1080)
 ap.add_argument('--bounces', type=int, default=5)
 ap.add_argument('--tonemap', default='FILMIC')
-ap.add_argument('--scene-flags', type=int, default=0)
+ap.add_argument('--scene-flags', type=int, default=8)
 ap.add_argument('--shards', default='1,2,4,8')
 a = ap.parse_args()
 sc = pta.HostScene.generate_ps5(a.tris, 0, a.scene_flags)
