@@ -308,6 +308,8 @@ typedef struct pt_counters {
     uint64_t deferred_casts;       /* closest-hit casts finished by k_wf_trace_wide (drain phase of k_wf_trace) */
     uint64_t exact_casts;          /* closest-hit casts k_wf_trace left to k_wf_trace_exact: rays whose direction has a component
                                     * below 8e-4, which the wavefront walker's slack does not cover (csrc/pt_integrator.h) */
+    uint64_t masked_casts;         /* of segments: ray_cast calls of bounces >= 1 that were NOT cast because the escape mask of the
+                                    * primitive the ray leaves proves them empty (csrc/pt_escape.h) */
 } pt_counters;
 
 int pt_get_timing(const pt_scene* scene, pt_timing* out);
@@ -334,6 +336,10 @@ typedef struct pt_scene_info {
     uint32_t light_grids;     /* lights whose shadow rays use a grid (all or none)    */
     uint64_t grid_refs;       /* list entries of all grids                            */
     float grid_build_seconds;
+    /* escape masks (csrc/pt_escape.h): proofs of misses for the rays that leave a primitive */
+    float escape_build_seconds;
+    uint32_t escape_prims;      /* primitives with a mask (the others: all directions "may hit") */
+    float escape_clear_fraction; /* of those primitives' 384 direction cells: proven empty */
 } pt_scene_info;
 int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out);
 
@@ -368,6 +374,11 @@ int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint
  * scene has no such grid; cell_off / refs are left null), pt_scene_grid_copy copies the n_cells + 1 cell offsets and
  * the n_refs list entries into caller-provided host arrays - for the tests, which compare them with the host builder's
  * (pth_origin_grid_build: the same lists byte for byte) and run the conservativeness checks on them. */
+/* The escape masks of a scene (csrc/pt_escape.h) as the device built them: 80 bytes per primitive - f32 normal (0 0 0: the
+ * primitive has no mask), f32 v0, two spare words, then six faces x 64 direction bits (bit = row * 8 + column, set = "may
+ * hit").  For the tests, which aim rays through clear cells and require brute force to find nothing. */
+int pt_scene_escape_copy(const pt_scene* scene, void* out, uint64_t bytes);
+
 struct pth_origin_grid;
 struct pth_grid_ref;
 int pt_scene_grid_header(const pt_scene* scene, uint32_t which, struct pth_origin_grid* out);

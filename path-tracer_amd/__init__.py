@@ -107,7 +107,7 @@ class Counters(C.Structure):
                                           "tris_tested", "shaded_hits", "rng_draws", "restarts",
                                           "max_nodes_per_cast", "casts_over_1k_nodes", "trace_nodes", "trace_tris",
                                           "shadow_skipped", "bounce0_hits", "bounce0_shadow_rays", "bounce0_tris",
-                                          "grid_tris", "bounce0_cam_tris", "deferred_casts", "exact_casts")]
+                                          "grid_tris", "bounce0_cam_tris", "deferred_casts", "exact_casts", "masked_casts")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -118,7 +118,8 @@ class SceneInfo(C.Structure):
                 ("n_leaf_refs", C.c_uint64), ("kd_depth", C.c_uint32), ("has_translucent", C.c_uint32),
                 ("kd_build_seconds", C.c_float), ("upload_seconds", C.c_float), ("device_bytes", C.c_uint64),
                 ("cam_grid_res", C.c_uint32), ("light_grids", C.c_uint32), ("grid_refs", C.c_uint64),
-                ("grid_build_seconds", C.c_float)]
+                ("grid_build_seconds", C.c_float), ("escape_build_seconds", C.c_float), ("escape_prims", C.c_uint32),
+                ("escape_clear_fraction", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -175,7 +176,7 @@ HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_s
 GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_prep_create", "pt_prep_destroy", "pt_scene_create_from_prep",
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_gather_tiles", "pt_render_gathered", "pt_local_pixel_count", "pt_local_pixel_map",
                "pt_render", "pt_render_device", "pt_debug_render", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
-               "pt_scene_get_info", "pt_get_cull_stats", "pt_scene_grid_header", "pt_scene_grid_copy", "pt_trace_rays", "pt_trace_rays_wavefront",
+               "pt_scene_get_info", "pt_get_cull_stats", "pt_scene_escape_copy", "pt_scene_grid_header", "pt_scene_grid_copy", "pt_trace_rays", "pt_trace_rays_wavefront",
                "pt_trace_rays_all", "pt_intersect_triangles",
                "pt_rng_words", "pt_eval_math", "pt_measure_copy_bandwidth", "pt_measure_gather_rate", "pt_last_error",
                "pt_version"]
@@ -259,6 +260,7 @@ def gpu_lib():
         L.pt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp]
         L.pt_trace_rays_wavefront.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, vp]
         L.pt_scene_grid_header.argtypes = [vp, C.c_uint32, vp]
+        L.pt_scene_escape_copy.argtypes = [vp, vp, C.c_uint64]
         L.pt_get_cull_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.pt_scene_grid_copy.argtypes = [vp, C.c_uint32, vp, vp]
         L.pt_trace_rays_all.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
@@ -553,6 +555,18 @@ class GpuScene:
         out = np.zeros(len(rays), dtype=HIT_DTYPE)
         check_gpu(self.lib.pt_trace_rays(self.handle, rays.ctypes.data, len(rays), out.ctypes.data))
         return out
+
+    def escape_masks(self):
+        """(normals [n, 3] (0: no mask), v0 [n, 3], bits [n, 6, 64] bool: True = 'may hit') as the device built them."""
+        import numpy as np
+        n = int(self.info().n_prims)
+        raw = np.zeros((n, 20), np.uint32)
+        check_gpu(self.lib.pt_scene_escape_copy(self.handle, raw.ctypes.data, raw.nbytes))
+        f = raw.view(np.float32)
+        normals, v0 = f[:, 0:3].copy(), np.stack([f[:, 3], f[:, 4], f[:, 5]], axis=1)
+        words = raw[:, 8:20].reshape(n, 6, 2)
+        bits = ((words[:, :, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool).reshape(n, 6, 64)
+        return normals, v0, bits
 
     def trace_wavefront(self, rays, start_prims=None, mode=0):
         """Closest hits through k_wf_trace itself (mode bit 0: entry lists from start_prims, bit 1: k_wf_trace_wide)."""

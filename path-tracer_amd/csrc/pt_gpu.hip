@@ -38,6 +38,7 @@
 #include "pt_integrator.h"
 #include "pt_wavefront.h"
 #include "pt_grid_kernels.h"
+#include "pt_escape_build.h"
 #include "pt_grid_build.h"
 #include "pthost.h"
 
@@ -1245,6 +1246,63 @@ void scene_upload(const pt_prep& P, int device, pt_scene& s) {
     D.texels = s.upload(P.texels.data(), P.texels.size());
     D.srgb_lut = s.upload(P.lut, 256);
     D.lights = s.upload(P.lights.data(), P.lights.size());
+    // ---- escape masks (pt_escape.h): built here, on the device, from the arrays just uploaded (one wavefront per primitive)
+    D.escape = nullptr;
+    s.info.escape_build_seconds = 0.f;
+    s.info.escape_prims = 0;
+    s.info.escape_clear_fraction = 0.f;
+    {
+        const char* esc_env = getenv("PT_ESCAPE");   // (read per scene: the tests switch it)
+        const bool esc_on = !(esc_env && *esc_env && atoi(esc_env) == 0);
+        const uint64_t n_prims = P.pos.size() / 3;
+        if (esc_on && n_prims > 0 && n_prims < (1ull << 28)) {
+            auto t_esc = std::chrono::steady_clock::now();
+            const size_t mark = s.allocations.size();
+            const uint64_t bytes_mark = s.info.device_bytes;
+            try {
+                void* buf = nullptr;
+                HIP_CHECK(hipMalloc(&buf, n_prims * 80));
+                s.allocations.push_back(buf);
+                s.info.device_bytes += n_prims * 80;
+                uint32_t* d_stats = nullptr;
+                HIP_CHECK(hipMalloc((void**)&d_stats, 16));
+                HIP_CHECK(hipMemset(d_stats, 0, 16));
+                // the largest distance a ray of this scene covers before it hits anything: the box diagonal, or camera to far corner
+                double diag2 = 0, cam2 = 0, amax = 0;
+                for (int a = 0; a < 3; ++a) {
+                    const double w = (double)D.bounds_max[a] - D.bounds_min[a], c = D.cam_c3[a];
+                    const double far = std::max(std::fabs(c - D.bounds_min[a]), std::fabs(c - D.bounds_max[a]));
+                    diag2 += w * w;
+                    cam2 += far * far;
+                    amax = std::max({amax, std::fabs((double)D.bounds_min[a]), std::fabs((double)D.bounds_max[a]), std::fabs(c)});
+                }
+                const double reach = std::sqrt(std::max(diag2, cam2));
+                EscBuildParams E{};
+                E.delta_in = (float)((double)PT_SLACK_K * reach + 4.0 * 5.9604645e-8 * amax);
+                E.slop_far = E.delta_in;
+                E.alpha_stop = [] { const char* e = getenv("PT_ESCAPE_ALPHA"); return e && *e ? (float)atof(e) : 0.04f; }();
+                E.r_near_scale = 2.0f;
+                const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_prims + 3) / 4, 256u * 64u);
+                hipLaunchKernelGGL(k_escape_build, dim3(blocks), dim3(256), 0, 0, D, E, (float4*)buf, (uint32_t)n_prims, d_stats);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipDeviceSynchronize());
+                uint32_t st[4] = {0, 0, 0, 0};
+                HIP_CHECK(hipMemcpy(st, d_stats, 16, hipMemcpyDeviceToHost));
+                (void)hipFree(d_stats);
+                D.escape = (const float4*)buf;
+                s.info.escape_prims = st[0];
+                s.info.escape_clear_fraction = st[0] ? (float)((double)st[1] / (384.0 * st[0])) : 0.f;
+            } catch (const GpuError&) {   // (no memory for them: the casts are simply made)
+                while (s.allocations.size() > mark) {
+                    (void)hipFree(s.allocations.back());
+                    s.allocations.pop_back();
+                }
+                s.info.device_bytes = bytes_mark;
+                D.escape = nullptr;
+            }
+            s.info.escape_build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_esc).count();
+        }
+    }
     auto upload_grid = [&](const pth_origin_grid& g, DevGrid& out) {
         memset(&out, 0, sizeof out);
         if (!g.enabled) return;
@@ -1348,6 +1406,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     HIP_CHECK(hipSetDevice(s.device));
     TileMap tm = make_tile_map(p, o, o.shard_rank);
     if (tm.n_local == 0) return;
+    // the scene as the kernels of THIS frame see it: the KD-tree pipeline (PT_FLAG_NO_GRIDS) - the cross-check of the parity
+    // tests - knows no escape masks either
+    DevScene dev = s.dev;
+    if (o.flags & PT_FLAG_NO_GRIDS) dev.escape = nullptr;
 
     // tile tables (cached per configuration: no host sync in steady state): the packed offset of every local tile
     // (sharded renders), then - PT_TILE_ORDER=morton - the order in which the wavefront integrator visits the local
@@ -1683,7 +1745,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         P1.sample_end = 1;
         pt_fastdiv_make(1u, P1.div_batch);
         HIP_CHECK(hipMemsetAsync((uint32_t*)s.pipe.block_mask.p + blocks64, 0, 4, stream));
-        hipLaunchKernelGGL(k_cam_block_mask, dim3((blocks64 * 64u + 255u) / 256u), dim3(256), 0, stream, s.dev, P1, d_tiles, blocks64,
+        hipLaunchKernelGGL(k_cam_block_mask, dim3((blocks64 * 64u + 255u) / 256u), dim3(256), 0, stream, dev, P1, d_tiles, blocks64,
                            (uint32_t*)s.pipe.block_mask.p, (uint8_t*)((uint32_t*)s.pipe.block_mask.p + blocks64 + 1u));
         HIP_CHECK(hipGetLastError());
         block_empty = (const uint32_t*)s.pipe.block_mask.p;
@@ -1697,9 +1759,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         if (mode == 0) {
             stage_begin(5);
             if (counting)
-                hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum, gctr);
+                hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(256), 0, stream, dev, P, d_tiles, accum, gctr);
             else
-                hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(256), 0, stream, s.dev, P, d_tiles, accum, gctr);
+                hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(256), 0, stream, dev, P, d_tiles, accum, gctr);
             HIP_CHECK(hipGetLastError());
             stage_end();
             ++launches;
@@ -1754,7 +1816,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     // (no k_wf_rng launch)
                 } else if (!rng_ahead || chunk_no == 0) {
                     stage_begin(0);
-                    hipLaunchKernelGGL(k_wf_rng, dim3((W.n_items + 255u) / 256u), dim3(256), 0, st_main, s.dev, W, d_tiles,
+                    hipLaunchKernelGGL(k_wf_rng, dim3((W.n_items + 255u) / 256u), dim3(256), 0, st_main, dev, W, d_tiles,
                                        rng_planes);
                     HIP_CHECK(hipGetLastError());
                     stage_end();
@@ -1770,7 +1832,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     HIP_CHECK(hipStreamWaitEvent(pipe.side_rng, pipe.ev_chunk, 0));
                     stage_stream = pipe.side_rng;
                     stage_begin(0);
-                    hipLaunchKernelGGL(k_wf_rng, dim3((Wn.n_items + 255u) / 256u), dim3(256), 0, pipe.side_rng, s.dev, Wn,
+                    hipLaunchKernelGGL(k_wf_rng, dim3((Wn.n_items + 255u) / 256u), dim3(256), 0, pipe.side_rng, dev, Wn,
                                        d_tiles, (uint4*)pipe.rng[(chunk_no + 1u) & 1u].p);
                     HIP_CHECK(hipGetLastError());
                     stage_end();
@@ -1814,7 +1876,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     } while (0)
 // k_wf_shade<ALPHA, COUNT, PRIMARY, GRID>
 #define PT_SHADE_ARGS                                                                                                         \
-    s.dev, W, d_tiles, (const float4*)q_in, shade_hits, (const uint4*)rng_planes, (const uint32_t*)pipe.draws.p, \
+    dev, W, d_tiles, (const float4*)q_in, shade_hits, (const uint4*)rng_planes, (const uint32_t*)pipe.draws.p, \
         q_out, (float4*)pipe.shadow.p, (float4*)pipe.contrib.p, (float*)s.staging_buf.p, shade_list,                 \
         (const uint32_t*)pipe.exact[b & 1].p, (const uint4*)pipe.hits.p, (uint32_t*)pipe.exact[(b + 1) & 1].p,      \
         (grid_mode >= 2 ? block_empty : (const uint32_t*)nullptr), wctr, gctr
@@ -1844,7 +1906,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                         if (prim && use_cam_grid) {   // camera rays: one grid lookup instead of a KD walk (pt_grid_kernels.h)
                             const dim3 g((W.n_items + 255u) / 256u);
 #define PT_LAUNCH_OGP(A, C)                                                                                                   \
-    hipLaunchKernelGGL((k_og_primary<A, C>), g, dim3(256), 0, st_main, s.dev, W, d_tiles, (uint4*)pipe.hits.p, \
+    hipLaunchKernelGGL((k_og_primary<A, C>), g, dim3(256), 0, st_main, dev, W, d_tiles, (uint4*)pipe.hits.p, \
                        (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, gctr)
                             if (alpha && counting) PT_LAUNCH_OGP(true, true);
                             else if (alpha) PT_LAUNCH_OGP(true, false);
@@ -1882,7 +1944,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             auto launch_exact = [&](hipStream_t st_exact) {
                                 const dim3 eg(W.exact_handover == 2u ? std::max(1u, (uint32_t)s.n_cu * exact_blocks / 8u) : (uint32_t)s.n_cu * 16u);
 #define PT_LAUNCH_EXACT(C, A, P)                                                                                               \
-    hipLaunchKernelGGL((k_wf_trace_exact<C, A, P>), eg, dim3(WF_EXACT_THREADS), 0, st_exact, s.dev, W, d_tiles, (const float4*)q_in, \
+    hipLaunchKernelGGL((k_wf_trace_exact<C, A, P>), eg, dim3(WF_EXACT_THREADS), 0, st_exact, dev, W, d_tiles, (const float4*)q_in, \
                        (uint4*)pipe.hits.p, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (uint32_t*)pipe.exact[b & 1].p, \
                        (const WfCounters*)wctr, gctr)
                                 if (prim) {
@@ -1914,7 +1976,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                                                    (uint32_t*)pipe.deferred.p, cap, wctr, b);
                                 HIP_CHECK(hipGetLastError());
                             } else {
-                                PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, s.dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
+                                PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
                                               (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (uint32_t*)pipe.deferred.p,
                                               (uint32_t*)pipe.exact[b & 1].p, wctr, gctr);
                             }
@@ -1940,7 +2002,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                                     HIP_CHECK(hipStreamWaitEvent(st_wide, pipe.ev_trace, 0));
                                 }
 #define PT_LAUNCH_WIDE(C, A)                                                                                                  \
-    hipLaunchKernelGGL((k_wf_trace_wide<C, A>), dim3(wide_grid), dim3(WF_THREADS), 0, st_wide, s.dev, W, d_tiles, (const float4*)q_in, \
+    hipLaunchKernelGGL((k_wf_trace_wide<C, A>), dim3(wide_grid), dim3(WF_THREADS), 0, st_wide, dev, W, d_tiles, (const float4*)q_in, \
                        wide_hits, (const uint4*)rng_planes, (uint32_t*)pipe.draws.p, (const uint32_t*)pipe.deferred.p,             \
                        (const WfCounters*)wctr, gctr)
                                 if (alpha && counting) PT_LAUNCH_WIDE(true, true);
@@ -2008,7 +2070,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     if (wf_refill_shadow) Ws.refill_min = std::min(64u, wf_refill_shadow);
                     if (wf_walk_shadow) Ws.walk_steps = wf_walk_shadow;
 #define PT_OGS_ARGS                                                                                                    \
-    s.dev, Ws, (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, \
+    dev, Ws, (const float4*)pipe.shadow.p, (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, \
         (uint32_t*)pipe.offgrid.p, wctr, gctr
                     if (grid_mode != 0) {
                         // what is left in the shadow queue: surfaces with a normal too long for the grids' margin
@@ -2037,7 +2099,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                         else hipLaunchKernelGGL((k_og_shadow_offgrid<false, true>), dim3((uint32_t)s.n_cu), dim3(256), 0, st_shadow, PT_OGS_ARGS);
                         HIP_CHECK(hipGetLastError());
                     } else {
-                        PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, s.dev, Ws, (float4*)pipe.shadow.p,
+                        PT_LAUNCH_AC(k_wf_shadow, s.shadow_blocks, dev, Ws, (float4*)pipe.shadow.p,
                                      (const float4*)pipe.contrib.p, q_out, (float*)s.staging_buf.p, (uint32_t*)pipe.offgrid.p, wctr, gctr);
                         // ... and the jobs it set aside: a shadow ray the wavefront walker does not take (normally a few per mille)
                         if (Ws.exact_handover) {
@@ -2163,7 +2225,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
                                  c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes,
                                  c.trace_nodes, c.trace_tris, c.shadow_skipped, c.bounce0_hits, c.bounce0_shadow_rays,
-                                 c.bounce0_tris, c.grid_tris, c.bounce0_cam_tris, c.deferred_casts, c.exact_casts};
+                                 c.bounce0_tris, c.grid_tris, c.bounce0_cam_tris, c.deferred_casts, c.exact_casts, c.masked_casts};
         if (getenv("PT_DEBUG_HIST")) {   // casts of k_wf_trace by length (bins of 64 node visits; bin 0 not counted)
             fprintf(stderr, "[pt] cast length histogram (x64 nodes):");
             for (int b = 1; b < 16; ++b) fprintf(stderr, " %llu", c.cast_hist[b]);
@@ -2640,6 +2702,16 @@ int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint
             memcpy(&o.v, &rest[i].z, 4);
             if (sphere) o.u = o.v = 0.f;
         }
+    });
+}
+
+int pt_scene_escape_copy(const pt_scene* scene, void* out, uint64_t bytes) {
+    return guarded([&] {
+        if (!scene || !out) fail(PT_ERR_INVALID, "pt_scene_escape_copy: null argument");
+        if (!scene->dev.escape) fail(PT_ERR_INVALID, "pt_scene_escape_copy: the scene has no escape masks");
+        if (bytes != (uint64_t)scene->dev.n_prims * 80u) fail(PT_ERR_INVALID, "pt_scene_escape_copy: %llu bytes expected", (unsigned long long)scene->dev.n_prims * 80ull);
+        HIP_CHECK(hipSetDevice(scene->device));
+        HIP_CHECK(hipMemcpy(out, scene->dev.escape, bytes, hipMemcpyDeviceToHost));
     });
 }
 

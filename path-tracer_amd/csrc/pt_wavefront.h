@@ -25,6 +25,7 @@
 #pragma once
 #include "pt_integrator.h"
 #include "pt_grid.h"
+#include "pt_escape.h"
 
 // Work item -> pixel / sample (see the item numbering in pt_gpu.hip).
 struct ItemRef {
@@ -1947,7 +1948,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
         const uint4 k = ((const uint4*)((const uint32_t*)chunk_hits + W.cap))[i];
         return unpack_hit(make_uint4(x, k.x, k.y, k.z), h);
     };
-    uint32_t n_draws = 0, n_new = 0, n_moot = 0, n_hits = 0, n_cam_tris = 0;
+    uint32_t n_draws = 0, n_new = 0, n_moot = 0, n_hits = 0, n_cam_tris = 0, n_masked = 0;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};   // (GRID: casts made here)
     __shared__ uint32_t sh_cnt[2][WF_SHADE_THREADS / 64];
     __shared__ uint32_t sh_base[2];
@@ -2133,6 +2134,19 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
             if (wf_rng_draw(rng, W, tile_offsets, rng_planes, item, draw++) > p) ended = true;
         }
         survive = !ended && bounce + 1 <= bounces;
+        // Escape mask of the primitive the ray leaves (pt_escape.h): a clear bit proves that the next ray_cast is empty, i.e.
+        // that the path ends with `colour + throughput x background` (mod.rs:184-186) - no record, no cast.  The background
+        // term must be added AFTER this bounce's lights (mod.rs:248-262 come first): here if the lights are added here
+        // (inline) or none can contribute; through the shadow queue only if the term is exactly zero (a black background).
+        if (survive && S.escape != nullptr && !surf.sphere && escape_proves_miss(S, PT_PRIM_INDEX(h.pid), next_o, next_d)) {
+            const f3 bg = mul_ew(next_thr, ld3(S.background));
+            const bool zero = bg.x == 0.f && bg.y == 0.f && bg.z == 0.f;
+            if (zero || !to_shadow) {
+                if (!zero) color = color + bg;
+                survive = false;
+                if (COUNT) n_masked++;
+            }
+        }
     }
     // ---- compaction: survivors -> queue[b+1], surface hits -> shadow queue.  One atomic per
     // workgroup and queue (wave ballots -> LDS -> one lane), not one per wavefront: the counter
@@ -2334,6 +2348,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
         atomicAdd(&gctr->shadow_skipped, (unsigned long long)n_moot);
     }
     if (COUNT && PRIMARY && n_hits) atomicAdd(&gctr->bounce0_hits, (unsigned long long)n_hits);
+    if (COUNT && n_masked) {   // (ray_cast calls the reference makes and this pipeline proves empty)
+        atomicAdd(&gctr->segments, (unsigned long long)n_masked);
+        atomicAdd(&gctr->masked_casts, (unsigned long long)n_masked);
+    }
     if (COUNT && GRID != 0) {
         atomicAdd(&gctr->segments, (unsigned long long)lc.segments);
         atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);
