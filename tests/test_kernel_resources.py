@@ -46,8 +46,9 @@ def test_hot_kernels_stay_within_their_register_and_scratch_budgets(tmp_path):
     assert b0["vgpr_count"] <= 170 and b0["private_segment_fixed_size"] <= 32, b0
     # ... and of translucent scenes (config 5)
     b0a = find(t, "k_wf_shadeILb1ELb0ELb1ELi3EE")
-    # (80 B in round 2; + the hit's id kept for the scene-box test and the optional entry word: 88 B)
-    assert b0a["vgpr_count"] <= 170 and b0a["private_segment_fixed_size"] <= 96, b0a
+    # (80 B in round 2; + the hit's id kept for the scene-box test and the optional entry word: 88 B; + the escape-mask lookup
+    # of round 4: 100 B)
+    assert b0a["vgpr_count"] <= 170 and b0a["private_segment_fixed_size"] <= 104, b0a
     # shading of the later bounces
     sh = find(t, "k_wf_shadeILb0ELb0ELb0ELi0EE")
     assert sh["vgpr_count"] <= 128 and sh["private_segment_fixed_size"] <= 96, sh
