@@ -310,6 +310,7 @@ typedef struct pt_counters {
                                     * below 8e-4, which the wavefront walker's slack does not cover (csrc/pt_integrator.h) */
     uint64_t masked_casts;         /* of segments: ray_cast calls of bounces >= 1 that were NOT cast because the escape mask of the
                                     * primitive the ray leaves proves them empty (csrc/pt_escape.h) */
+    uint64_t bounce0_masked;       /* of masked_casts: found by the bounce-0 kernel (paths that never enter a queue) */
 } pt_counters;
 
 int pt_get_timing(const pt_scene* scene, pt_timing* out);

@@ -107,7 +107,7 @@ class Counters(C.Structure):
                                           "tris_tested", "shaded_hits", "rng_draws", "restarts",
                                           "max_nodes_per_cast", "casts_over_1k_nodes", "trace_nodes", "trace_tris",
                                           "shadow_skipped", "bounce0_hits", "bounce0_shadow_rays", "bounce0_tris",
-                                          "grid_tris", "bounce0_cam_tris", "deferred_casts", "exact_casts", "masked_casts")]
+                                          "grid_tris", "bounce0_cam_tris", "deferred_casts", "exact_casts", "masked_casts", "bounce0_masked")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -135,7 +135,7 @@ static inline void pt_fastdiv_make(uint32_t d, uint32_t (&ms)[2]) {
 struct DevCounters {
     unsigned long long samples, segments, shadow_rays, nodes_visited, tris_tested, shaded_hits, rng_draws,
         restarts, max_nodes_per_cast, casts_over_1k_nodes, trace_nodes, trace_tris, shadow_skipped,
-        bounce0_hits, bounce0_shadow_rays, bounce0_tris, grid_tris, bounce0_cam_tris, deferred_casts, exact_casts, masked_casts;
+        bounce0_hits, bounce0_shadow_rays, bounce0_tris, grid_tris, bounce0_cam_tris, deferred_casts, exact_casts, masked_casts, bounce0_masked;
     unsigned long long stamps[8];  // diagnostics: phase cycles of a -DWF_STAMPS build; else [0,1,3,4,5] rounds / steps / time of k_wf_trace_wide
     unsigned long long cast_hist[16];  // k_wf_trace casts by nodes visited, 64 per bin (PT_DEBUG_HIST prints it)
 #ifdef WF_EXIT_TIMES

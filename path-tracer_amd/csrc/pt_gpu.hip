@@ -1104,7 +1104,7 @@ bool device_grid_build(pt_scene& s, const pt_prep::GridJob& job, const float* d_
             const uint32_t v = bsum[b];
             if (run > 0xffffffffull) break;
             bsum[b] = (uint32_t)run;
-            run += v;
+            run += v == 0xffffffffu ? 0x100000000ull : v;   // (a saturated block sum: the grid is given up below)
         }
         const uint64_t total = run;
         if (total > 0xffffffffull || bytes_used + (double)off_bytes + 8.0 * (double)total > budget) {
@@ -1501,6 +1501,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     if (p.bounces > 4096u) fail(PT_ERR_INVALID, "profile.bounces %u is out of range (at most 4096)", p.bounces);
     const bool use_cam_grid = !(o.flags & PT_FLAG_NO_GRIDS) && s.dev.cam_grid.res != 0;
     const bool use_light_grids = !(o.flags & PT_FLAG_NO_GRIDS) && s.dev.all_lights_gridded != 0;
+    // bounce 0 as ONE kernel (k_wf_shade<GRID >= 2>: camera cast through the camera grid, shadow casts through the light grids).
+    // The camera-grid cull belongs to that kernel: its mask is computed, its wavefronts skip empty blocks and k_accumulate
+    // adds the background for their pixels under this one condition (round-3 advisory: three places derived it separately).
+    const bool bounce0_fused = use_cam_grid && use_light_grids;
     const uint32_t blocks64 = tm.n_local_tiles * (o.tile_w / 8u) * (o.tile_h / 8u);
     // staging budget (radiance 12 B + RNG block 64 B per work item [+ queues]); default 32 GiB of 288 GB
     static const uint64_t budget = [] {
@@ -1633,7 +1637,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                                                                                                         // (wf_exact_words), one list per bounce parity
                       // casts left to k_wf_trace_wide: at most one per lane in flight when the queue runs dry
                       // (4 B the queue index + 20 B a hit + 4 B the progress of the walk: wf_list_* in pt_wavefront.h)
-                      (!(use_cam_grid && use_light_grids) || w.block_mask.try_ensure((size_t)blocks64 * 4u + 4u + tm.n_local)) &&
+                      (!bounce0_fused || w.block_mask.try_ensure((size_t)blocks64 * 4u + 4u + tm.n_local)) &&
                       (!wf_defer ||
                        w.deferred.try_ensure((wf_allwide && !alpha ? (size_t)cap : (size_t)s.trace_blocks * WF_THREADS) * 4u *
                                              (alpha ? WF_LIST_WORDS_ALPHA : WF_LIST_WORDS_OPAQUE)));
@@ -1739,7 +1743,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         return e && *e ? atoi(e) != 0 : true;
     }();
     const uint32_t* block_empty = nullptr;
-    if (cam_cull && mode == 2 && use_cam_grid && use_light_grids && !counting) {
+    if (cam_cull && mode == 2 && bounce0_fused && !counting) {
         RenderParams P1 = P;
         P1.sample_begin = 0;
         P1.sample_end = 1;
@@ -1778,7 +1782,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 const char* e = getenv("PT_OG_FUSE_RNG");
                 return e && *e ? atoi(e) != 0 : true;
             }();
-            const bool fused_rng = fuse_rng && use_cam_grid && use_light_grids;
+            const bool fused_rng = fuse_rng && bounce0_fused;
             const bool rng_ahead = !fused_rng && wf_overlap && total_items > cap && pipe.side_rng != nullptr;
             uint32_t chunk_no = 0;
             for (uint32_t base = 0; base < total_items; base += cap, ++chunk_no) {
@@ -1852,7 +1856,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                         const char* e = getenv("PT_OG_INLINE_ALL");
                         return e && *e ? atoi(e) : 0;
                     }();
-                    const int grid_mode = use_light_grids ? ((prim && use_cam_grid) ? (fused_rng ? 3 : 2) : (inline_later ? 1 : 0)) : 0;
+                    const int grid_mode = (prim && bounce0_fused) ? (fused_rng ? 3 : 2) : (use_light_grids && inline_later ? 1 : 0);
 #define PT_LAUNCH_ACP(kernel, grid, threads, ...)                                                                                      \
     do {                                                                                                                               \
         if (prim && alpha && counting)                                                                                                  \
@@ -2225,7 +2229,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         s.counters = pt_counters{c.samples, c.segments, c.shadow_rays, c.nodes_visited, c.tris_tested, c.shaded_hits,
                                  c.rng_draws, c.restarts, c.max_nodes_per_cast, c.casts_over_1k_nodes,
                                  c.trace_nodes, c.trace_tris, c.shadow_skipped, c.bounce0_hits, c.bounce0_shadow_rays,
-                                 c.bounce0_tris, c.grid_tris, c.bounce0_cam_tris, c.deferred_casts, c.exact_casts, c.masked_casts};
+                                 c.bounce0_tris, c.grid_tris, c.bounce0_cam_tris, c.deferred_casts, c.exact_casts, c.masked_casts, c.bounce0_masked};
         if (getenv("PT_DEBUG_HIST")) {   // casts of k_wf_trace by length (bins of 64 node visits; bin 0 not counted)
             fprintf(stderr, "[pt] cast length histogram (x64 nodes):");
             for (int b = 1; b < 16; ++b) fprintf(stderr, " %llu", c.cast_hist[b]);

@@ -68,10 +68,13 @@ __global__ __launch_bounds__(256) void k_og_raster(GridParams P, const float* __
 
 #define OG_SCAN_BLOCK 1024u   // cells per block (256 threads x 4)
 
+// (summed in 64 bits and SATURATED: 1024 cells that every one of several million large primitives overlaps hold more than
+// 2^32 references between them - a wrapped sum would make the host's total too small and pass 1 write past the list array;
+// the host rejects a grid with a saturated block - round-3 advisory)
 __global__ __launch_bounds__(256) void k_og_block_sum(const uint32_t* __restrict__ cnt, uint64_t n_cells, uint32_t* __restrict__ block_sum) {
-    __shared__ uint32_t sh[256];
+    __shared__ unsigned long long sh[256];
     const uint64_t base = (uint64_t)blockIdx.x * OG_SCAN_BLOCK + threadIdx.x * 4u;
-    uint32_t s = 0;
+    unsigned long long s = 0;
     for (uint32_t k = 0; k < 4u; ++k)
         if (base + k < n_cells) s += cnt[base + k];
     sh[threadIdx.x] = s;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void k_og_block_sum(const uint32_t* __restrict
         if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
         __syncthreads();
     }
-    if (threadIdx.x == 0) block_sum[blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = sh[0] > 0xffffffffull ? 0xffffffffu : (uint32_t)sh[0];
 }
 
 // cnt[c] = block_off[block] + exclusive prefix inside the block

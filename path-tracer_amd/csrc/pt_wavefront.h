@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
         if (lstate == WF_LANE_DONE) complete();
         WF_STAMP(st_done);
         // ---- drain phase: once the queue has nothing left for this wavefront, a cast that has been going for
-        // defer_age iterations is handed to k_wf_trace_wide (16 lanes per cast) instead of keeping the wavefront - and,
+        // defer_age iterations is handed to k_wf_trace_wide (WF_WIDE_LANES = 32 lanes per cast) instead of keeping the wavefront - and,
         // at the end, the whole launch - waiting for one lane: the last 1 % of the wavefronts of a launch used to leave
         // 0.2 ... 0.5 ms after the median one, a fifth of the launch for an eighth of a 1080p frame.
         if (!PRIMARY && W.defer_age != 0u) {
@@ -1922,7 +1922,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
     // index_list (bounces >= 1): null - the whole queue, entries marked WF_HIT_PENDING left out; else the entries to shade:
     // the hand-over list of k_wf_trace, whose casts k_wf_trace_wide has finished by now - `hits` is then that list's
     // own plane (W.list_cap records, by list position).  The pass over the queue runs WHILE k_wf_trace_wide walks
-    // those few long casts (16 lanes each, a launch bound by its longest cast).  Behind that list, in the same launch, the
+    // those few long casts (WF_WIDE_LANES = 32 lanes each, a launch bound by its longest cast).  Behind that list, in the same launch, the
     // exact list (k_wf_trace_exact, pt_wavefront.h wf_exact_words): word by list position, the rest of the hit in the chunk's
     // own plane (chunk_hits) at the queue index.  exact_next: the exact list of the NEXT bounce - a survivor whose new ray the
     // wavefront walker will not take (slack_is_capped) is listed here, where the ray is made, so that k_wf_trace_exact can
@@ -2351,6 +2351,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
     if (COUNT && n_masked) {   // (ray_cast calls the reference makes and this pipeline proves empty)
         atomicAdd(&gctr->segments, (unsigned long long)n_masked);
         atomicAdd(&gctr->masked_casts, (unsigned long long)n_masked);
+        if (PRIMARY) atomicAdd(&gctr->bounce0_masked, (unsigned long long)n_masked);
     }
     if (COUNT && GRID != 0) {
         atomicAdd(&gctr->segments, (unsigned long long)lc.segments);

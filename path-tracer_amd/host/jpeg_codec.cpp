@@ -188,10 +188,17 @@ struct Decoder {
     }
 
     // ---------------------------------------------------------------- block decoders
+    // The DC predictor of a component: a sum of up to 2^26 differences of 11 bits each.  A conforming stream keeps it within the
+    // 16-bit coefficient range (T.81 F.1.2.1); a crafted one would walk a plain `int` into signed overflow - rejected instead.
+    int dc_pred(int pred, int diff) {
+        const long long p = (long long)pred + diff;
+        if (p < -32768 || p > 32767) bad("DC coefficient out of range");
+        return (int)p;
+    }
     void block_baseline(Comp& c, int16_t* b) {
         const int t = decode_huff(dc[c.td]);
         if (t > 11) bad("bad DC magnitude");
-        c.pred += extend(get_bits(t), t);
+        c.pred = dc_pred(c.pred, extend(get_bits(t), t));
         b[0] = (int16_t)c.pred;
         for (int k = 1; k < 64;) {
             const int rs = decode_huff(ac[c.ta]), r = rs >> 4, s = rs & 15;
@@ -209,8 +216,8 @@ struct Decoder {
     void block_dc_first(Comp& c, int16_t* b, int al) {
         const int t = decode_huff(dc[c.td]);
         if (t > 11) bad("bad DC magnitude");
-        c.pred += extend(get_bits(t), t);
-        b[0] = (int16_t)(c.pred * (1 << al));
+        c.pred = dc_pred(c.pred, extend(get_bits(t), t));
+        b[0] = (int16_t)((int64_t)c.pred * ((int64_t)1 << al));   // (al <= 13; the product in 64 bits, truncated like libjpeg's cast)
     }
     void block_dc_refine(int16_t* b, int al) {
         if (get_bit()) b[0] = (int16_t)(b[0] | (1 << al));
@@ -373,7 +380,9 @@ struct Decoder {
             const int32_t d0 = in[c] * q[c], d1 = in[8 + c] * q[8 + c], d2 = in[16 + c] * q[16 + c], d3 = in[24 + c] * q[24 + c],
                           d4 = in[32 + c] * q[32 + c], d5 = in[40 + c] * q[40 + c], d6 = in[48 + c] * q[48 + c], d7 = in[56 + c] * q[56 + c];
             if ((d1 | d2 | d3 | d4 | d5 | d6 | d7) == 0) {
-                const int32_t dcv = d0 * (1 << P1);
+                // (d0 = coefficient x a 16-bit quantiser entry can reach 2^31: the shift in 64 bits, the store truncated like the
+                // general path's descale())
+                const int32_t dcv = (int32_t)((int64_t)d0 * (1 << P1));
                 for (int r = 0; r < 8; ++r) ws[8 * r + c] = dcv;
                 continue;
             }

@@ -415,8 +415,9 @@ static void kd_build(const pt_scene_desc& d, pth_kdtree& out) {
     // it.  MEASURED (profiles/r03_experiments.txt item 3): any non-zero padding ends the "a primitive that only touches
     // a split plane stays on one side" economy at shared mesh edges - +45 % nodes, +43 % leaf references, +10 % node
     // visits per ray - and costs 4 % of the frame on config 3, 9 % in the closed room.  The default is therefore 0 (exact
-    // bounds), with the walk's slack along the ray raised from 1e-5 to 1e-3 instead (PT_EXIT_REL, csrc/pt_integrator.h),
-    // which covers the case found and all but rays within 0.02 degrees of a split plane.
+    // bounds); the walkers cover the case instead (csrc/pt_integrator.h, "slop model"): the wavefront walker's slack is the
+    // ray's own, PT_SLACK_K x the largest |1 / d_axis| between PT_SLACK_MIN and PT_SLACK_MAX, and a ray that would need
+    // more than PT_SLACK_MAX - a direction component below 8e-4 - leaves it for the fat-ray walker (k_wf_trace_exact).
     const float pad_scale = env_float("PT_KD_PAD", 0.f);
     std::vector<float> pads(n * 3);
     for (size_t i = 0; i < n; ++i)

@@ -780,7 +780,7 @@ def test_config3_full_size(pta, oracle, ps5_scene):
     g.render(prof)
     blocks, empty = g.cull_stats()
     assert abs(empty / blocks - 0.388) < 0.02   # (blocks: the 8x8 blocks of the 32x32 tiles that cover the image)
-    # the drain phase of the persistent trace launches handed casts to k_wf_trace_wide (16 lanes per cast), and the
+    # the drain phase of the persistent trace launches handed casts to k_wf_trace_wide (32 lanes per cast), and the
     # whole frame equals the megakernel's, which walks every cast with one lane from start to end
     assert c["deferred_casts"] > 0
     rgb_m, acc_m = g.render(prof, pta.Opts.make(flags=pta.PT_FLAG_MEGAKERNEL))

@@ -244,6 +244,19 @@ def test_jpeg_errors_are_errors(pta):
     sof = good.index(b"\xff\xc0")
     assert rc(good[:sof + 4] + b"\x0c" + good[sof + 5:]) != 0 and b"12-bit" in lib.pth_last_error()
     assert rc(good[:sof + 5] + b"\xff\xff\xff\xff" + good[sof + 9:]) != 0   # 65535 x 65535 pixels claimed by a 1 KB file
+    # 16-bit quantiser tables with the largest entries: coefficient x 65535 reaches 2^31 - the DC-only shortcut of the inverse
+    # DCT must not overflow an int (round-3 advisory); decodes to something, or fails cleanly
+    dqt = good.index(b"\xff\xdb")
+    seg_len = int.from_bytes(good[dqt + 2:dqt + 4], "big")
+    n_tables = (seg_len - 2) // 65
+    wide = b"".join(bytes([0x10 | t]) + b"\xff\xff" * 64 for t in range(n_tables))
+    crafted = good[:dqt + 2] + (2 + len(wide)).to_bytes(2, "big") + wide + good[dqt + 2 + seg_len:]
+    rc(crafted)
+    # a DC predictor walked out of the 16-bit coefficient range is an error (it used to be a signed overflow): every Huffman
+    # coded DC difference replaced by the largest one is the quickest way there - scan bytes set to 0xfe
+    sos = good.index(b"\xff\xda")
+    hdr = int.from_bytes(good[sos + 2:sos + 4], "big")
+    rc(good[:sos + 2 + hdr] + b"\xfe" * (len(good) - sos - 2 - hdr - 2) + b"\xff\xd9")
     rng = np.random.default_rng(3)
     for _ in range(300):   # random damage decodes to something or fails cleanly
         d = bytearray(good)

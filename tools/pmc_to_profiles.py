@@ -6,9 +6,16 @@ profiles/<tag>_pmc.json and refresh profiles/latest_traffic.json (read by bench.
 """
 import csv, glob, json, sys
 from collections import defaultdict
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import kernel_source_sha16   # (the record is only quoted by bench.py for the device code it was taken from)
 
 no_latest = "--no-latest" in sys.argv   # (a workload other than the headline's: profiles/latest_traffic.json stays)
-argv = [a for a in sys.argv if a != "--no-latest"]
+scene_flags = 0
+for a in sys.argv:
+    if a.startswith("--scene-flags="):
+        scene_flags = int(a.split("=")[1])
+argv = [a for a in sys.argv if a != "--no-latest" and not a.startswith("--scene-flags=")]
 src, tag = argv[1], argv[2]
 workload = [int(v) for v in argv[3:9]]
 acc = defaultdict(lambda: defaultdict(float))
@@ -56,18 +63,19 @@ for name, c in acc.items():
     }
 # the grid build of pt_scene_create (namespace ogb) runs once per scene in front of the timed region: its own section
 setup = {k: out.pop(k) for k in list(out) if k.startswith("ogb::")}
-json.dump({"workload": workload, "kernels": out, "setup_kernels": setup}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+json.dump({"workload": workload, "scene_flags": scene_flags, "kernels": out, "setup_kernels": setup}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 dominant = max(out, key=lambda k: out[k]["kernel_ms_profiled"])
 t = out[dominant]
 if not no_latest:
-  json.dump({"workload": workload, "kernel": dominant, "hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
+  json.dump({"workload": workload, "scene_flags": scene_flags, "kernel_source_sha16": kernel_source_sha16(), "kernel": dominant, "hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
            "tcp_accesses_per_cu_cycle": t["tcp_accesses_per_cu_cycle"],
            "valu_insts_per_cu_cycle": t["valu_insts_per_cu_cycle"],
            "active_lanes_per_valu_inst": t["active_lanes_per_valu_inst"],
            # every kernel's figures: bench.py reports the one with the largest time in ITS run, which may differ
            "kernels": {k: {"hbm_bytes_per_launch": round(v["hbm_bytes_per_launch"]),
                            "valu_insts_per_cu_cycle": v["valu_insts_per_cu_cycle"],
-                           "active_lanes_per_valu_inst": v["active_lanes_per_valu_inst"]} for k, v in out.items()},
+                           "active_lanes_per_valu_inst": v["active_lanes_per_valu_inst"],
+                           "kernel_ms_profiled": v["kernel_ms_profiled"]} for k, v in out.items()},
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_profile.sh); bytes = "
                      "(2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per 128 B "
                      "request); calibration in this pipeline: k_accumulate reads 12 B/sample -> FETCH_SIZE reads 0.48x",
