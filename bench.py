@@ -225,8 +225,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # (the FIRST frame of a configuration runs in fixed-budget chunks and counts what every bounce produces; the frame after it
+    # allocates the queues those counts ask for - pt_gpu.hip "frame plan".  Steady state is what the metric is quoted on: a
+    # warm-up of at least two frames, each complete before the next is planned; --warmup 0 times the cold frames)
+    warm_frames = 0 if args.warmup == 0 else max(2, args.warmup)
+    for _ in range(warm_frames):
         step()
+        torch.cuda.synchronize()
     for k in stage_ms:
         stage_ms[k] = 0.0
     for k in launches:
@@ -238,6 +243,7 @@ def main():
         step(with_events=k < ev_steps)
     fence()
     elapsed = time.perf_counter() - t0
+    q_info = gscene.info().as_dict()
     render_ms = sum(a.elapsed_time(b) for a, b, _ in ev_render) / args.steps     # this rank's frame (device time)
     gather_ms = sum(b.elapsed_time(c) for _, b, c in ev_render) / args.steps if world > 1 else 0.0
     per_rank = None
@@ -466,9 +472,9 @@ def main():
         gscene.close()
         scene0 = pta.HostScene.generate_ps5(args.tris, 0, 0)
         g0 = pta.GpuScene(scene0, device=local_rank)
-        for _ in range(max(1, args.warmup)):
+        for _ in range(max(2, args.warmup)):
             g0.render_device(prof, opts_plain, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             g0.render_device(prof, opts_plain, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
@@ -507,6 +513,10 @@ def main():
                                         "frac_of_casts_of_bounces_ge_1": round((counters["masked_casts"] / max(1, counters["segments"] - counters["samples"])), 4)
                                         if counters else None},
                        "exact_walker_casts": (counters or {}).get("exact_casts"),
+                       # device memory of the path queues during the timed frames (sized by an earlier frame's counts when planned)
+                       "queues": {"gib": round(q_info["queue_bytes"] / 2**30, 3), "chunk_items": q_info["queue_chunk_items"],
+                                  "chunks_per_frame": -(-(args.width * args.height * args.spp) // max(1, q_info["queue_chunk_items"])) if world == 1 else None,
+                                  "planned": bool(q_info["frame_planned"]), "warm_frames": warm_frames},
                        "parallelism": f"{world} x tile-sharded (32x32 interleaved)" + (
                            "" if world == 1 else ", RCCL all-gather of u8 framebuffer" if args.backend == "nccl"
                            else f", {args.backend} all-gather through host memory (REHEARSAL on {len(set(devices))} GPU(s), not an RCCL run)"),

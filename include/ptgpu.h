@@ -341,6 +341,12 @@ typedef struct pt_scene_info {
     float escape_build_seconds;
     uint32_t escape_prims;      /* primitives with a mask (the others: all directions "may hit") */
     float escape_clear_fraction; /* of those primitives' 384 direction cells: proven empty */
+    /* the path queues of the LAST frame rendered from this scene (csrc/pt_gpu.hip, "frame plan"): the first frame of a
+     * configuration runs in chunks of a fixed budget (PT_QUEUE_GIB, default 16) with every queue as long as the chunk and
+     * counts what each bounce produces; later frames of the same configuration get queues of exactly those lengths */
+    uint64_t queue_bytes;        /* device memory held by the queues, hit / shadow records, RNG planes and lists */
+    uint32_t queue_chunk_items;  /* work items (pixel samples) per pass over the bounces                        */
+    uint32_t frame_planned;      /* 1: sized from an earlier frame's counts; 0: first frame of its configuration */
 } pt_scene_info;
 int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out);
 

@@ -119,7 +119,8 @@ class SceneInfo(C.Structure):
                 ("kd_build_seconds", C.c_float), ("upload_seconds", C.c_float), ("device_bytes", C.c_uint64),
                 ("cam_grid_res", C.c_uint32), ("light_grids", C.c_uint32), ("grid_refs", C.c_uint64),
                 ("grid_build_seconds", C.c_float), ("escape_build_seconds", C.c_float), ("escape_prims", C.c_uint32),
-                ("escape_clear_fraction", C.c_float)]
+                ("escape_clear_fraction", C.c_float), ("queue_bytes", C.c_uint64), ("queue_chunk_items", C.c_uint32),
+                ("frame_planned", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

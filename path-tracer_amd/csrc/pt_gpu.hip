@@ -214,6 +214,16 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t* __restrict__ ga
     for (uint32_t b = 0; b < elem_bytes; ++b) d[b] = s[b];
 }
 
+// The counts of one chunk, gathered into one line of the frame's statistics (render_device, frame plan).
+__global__ void k_wf_stats(const WfCounters* __restrict__ ctr, uint32_t levels, uint32_t* __restrict__ out) {
+    const uint32_t b = threadIdx.x;
+    if (b >= levels) return;
+    out[4 * b + 0] = ctr[b].queue_count;
+    out[4 * b + 1] = ctr[b].shadow_count;
+    out[4 * b + 2] = ctr[b].exact_count;
+    out[4 * b + 3] = b == 0 ? ctr[0].overflow : ctr[b].offgrid_count;
+}
+
 // ------------------------------------------------------------------ test-hook kernels
 __device__ __forceinline__ void store_hit(pt_hit& o, const RawHit& h) {
     o.prim = (int32_t)PT_PRIM_INDEX(h.pid);
@@ -502,6 +512,30 @@ struct pt_scene {
                    ev_exact = nullptr, ev_exact_go = nullptr;
     };
     mutable WfPipe pipe;
+    // What a frame of one configuration produced: records per queue and bounce, per chunk of work items.  A frame is a pure
+    // function of (scene, profile, options) - the seeds are the pixels' - so the counts of one frame are those of every later
+    // one: the FIRST frame of a configuration runs in chunks small enough for a fixed budget with every queue as long as the
+    // chunk, the later ones get queues as long as the records that exist (render_device, "frame plan").
+    struct FrameStats {
+        uint32_t cap_items = 0, n_slots = 0, levels = 0;   // the chunking the numbers were taken with; (batch, chunk) slots; bounces + 2
+        uint32_t* host = nullptr;                         // pinned: n_slots x levels x 4 words (queue, shadow, exact, offgrid | overflow)
+        hipEvent_t done = nullptr;
+        bool pending = false, valid = false, planned = false;
+        std::vector<uint32_t> first_item_of_slot;         // (which chunk a slot was)
+        // the plan made from them: work items per chunk, records per queue / hit / shadow / exact array, the bounces whose
+        // shadow casts go inline; fresh until its buffers have been allocated once (buffers much larger are given back then)
+        uint32_t plan_cap = 0, plan_q[2] = {0, 0}, plan_h = 0, plan_s = 0, plan_e = 0;
+        std::vector<uint8_t> plan_inline;
+        bool plan_fresh = false, plan_failed = false;   // (failed: the device could not provide the plan's buffers)
+        ~FrameStats() {
+            if (host) (void)hipHostFree(host);
+            if (done) (void)hipEventDestroy(done);
+        }
+    };
+    mutable std::map<std::vector<uint64_t>, std::unique_ptr<FrameStats>> frame_stats;
+    mutable DeviceBuffer stats_dev;
+    mutable uint64_t queue_bytes_last = 0;   // bytes of the path queues of the last frame (pt_scene_get_info)
+    mutable uint32_t queue_chunk_last = 0, frame_planned_last = 0;
     mutable int trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
     mutable uint32_t last_mask_blocks = 0;   // blocks of the last frame's camera-grid cull table (0: no cull in that frame)
     mutable uint32_t wf_cap_ok = 0;   // largest queue capacity the device provided so far (0: not tried)
@@ -517,6 +551,7 @@ struct pt_scene {
 
     ~pt_scene() {
         (void)hipSetDevice(device);
+        frame_stats.clear();
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
         if (capture_stream) (void)hipStreamDestroy(capture_stream);
         for (void* p : allocations) (void)hipFree(p);
@@ -1513,9 +1548,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     }();
     static const uint32_t wf_cap = [] {
         const char* e = getenv("PT_WF_CHUNK");
-        // 320 Mi work items = 80 GiB of queues (256 B per item) of the 288 GB: a whole 1080p x 128 spp frame is
-        // ONE chunk (every extra chunk repeats the ~13 persistent launches and their drain phases: 60.9 ms
-        // against 63.0 ms for two chunks of 128 Mi)
+        // the most work items one pass over the bounces may take, whatever the budgets of the frame plan below allow
+        // (every extra chunk repeats the ~13 persistent launches and their drain phases: 60.9 ms against 63.0 ms for
+        // two chunks of 128 Mi - round 2)
         return (uint32_t)(e && *e ? atof(e) : 320.0 * 1024 * 1024);
     }();
     static const bool wf_overlap = [] {    // shadow(b) on a side stream beside trace(b+1); PT_WF_OVERLAP=0 serialises
@@ -1594,13 +1629,15 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         s.staging_buf.ensure((size_t)batch * tm.n_local * 12);
     }
     uint32_t cap = 0;
+    // capacities (records) of what is indexed by a queue position: the two path queues, the hit records (+ the alpha walk's draw
+    // counts), the shadow records (+ contrib planes, off-grid list), the exact lists
+    uint32_t cap_q[2] = {0, 0}, cap_h = 0, cap_s = 0, cap_e = 0;
+    std::vector<uint8_t> inline_at(p.bounces + 2, 0);   // bounces >= 1 whose shadow casts run inside the shade kernel
+    pt_scene::FrameStats* fs = nullptr;
+    bool multi_chunk = false, rng_one_plane = false;
+    uint32_t stats_slots = 0;
     if (mode == 2) {
         uint64_t items_per_batch = (uint64_t)blocks64 * 64u * batch;
-        // chunks are whole 64-item groups
-        cap = (uint32_t)std::min<uint64_t>(items_per_batch, std::max<uint32_t>(64u, wf_cap & ~63u));
-        // a device that once could not provide the full-size queues is not asked again on every frame (each
-        // failed attempt costs several synchronising hipMalloc / hipFree calls)
-        if (s.wf_cap_ok) cap = std::min(cap, s.wf_cap_ok);
         if (s.trace_blocks == 0) {
             int a = 0, b = 0, c = 0, d = 0;
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_wf_trace<false, false, false>, WF_THREADS, 0));
@@ -1618,41 +1655,222 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             }
         }
         pt_scene::WfPipe& w = s.pipe;
-        w.ctr.ensure(sizeof(WfCounters) * (p.bounces + 3));
-        // The queues: 256 B per work item (+32 B for the second copy of the RNG planes of multi-chunk batches:
-        // words 0-7 of every item's ChaCha block, two 16-byte planes, so that the next chunk's k_wf_rng can
-        // run underneath the current chunk's bounces).  A device that cannot provide them (shared GPU) gets
-        // half-size chunks, and so on, down to 1 Mi items.
-        bool multi_chunk = false;
+        const uint32_t levels = p.bounces + 3;
+        w.ctr.ensure(sizeof(WfCounters) * levels);
+        const size_t lights = std::max(1u, s.dev.n_lights);
+        static const bool fuse_rng_env = [] {
+            const char* e = getenv("PT_OG_FUSE_RNG");
+            return e && *e ? atoi(e) != 0 : true;
+        }();
+        // (the fused bounce-0 kernel keeps words 0-3 of the items' ChaCha blocks in registers: one 16-byte plane per item)
+        rng_one_plane = fuse_rng_env && bounce0_fused;
+        // ---- The frame plan.  Bytes per work item when nothing is known (every queue as long as the chunk): two path queues of
+        // 64 B (+ the entry word), 20 B hit, 64 B shadow record + 16 B per light, the RNG plane(s), draws, off-grid and exact lists.
+        const uint64_t per_item = 68u * 2u + 20u + 64u + 16u * lights + (rng_one_plane ? 16u : 32u) + (alpha ? 4u : 0u) + 4u + 16u;
+        // (read per frame: the tests change them)
+        const double first_gib = [] { const char* e = getenv("PT_QUEUE_GIB"); return e && *e ? atof(e) : 16.0; }();
+        const double steady_gib = [first_gib] { const char* e = getenv("PT_QUEUE_STEADY_GIB"); return e && *e ? atof(e) : first_gib; }();
+        static const bool inline_auto = [] { const char* e = getenv("PT_OG_INLINE_AUTO"); return !(e && *e && atoi(e) == 0); }();
+        const uint32_t max_items = (uint32_t)std::min<uint64_t>(items_per_batch, std::max<uint32_t>(64u, wf_cap & ~63u));
+        std::vector<uint64_t> stat_key = {p.width, p.height, p.samples, p.bounces, (uint64_t)p.brdf,
+                                          o.flags & (PT_FLAG_NO_GRIDS | PT_FLAG_MEGAKERNEL | PT_FLAG_COUNTERS), (uint64_t)bounce0_fused, o.shard_rank, o.shard_count, o.tile_w, o.tile_h, batch, (uint64_t)max_items};
+        static const bool graphs_on = [] {   // (frames replayed from a captured graph keep the first frame's chunking: no plan)
+            const char* e = getenv("PT_GRAPH");
+            return e && *e ? atoi(e) != 0 : PT_GRAPH_DEFAULT;
+        }();
+        // the chunk of the first frame: what fits the first-frame budget
+        uint32_t cap_a = (uint32_t)std::min<uint64_t>(max_items, std::max<uint64_t>(1u << 20, (uint64_t)(first_gib * 1073741824.0) / per_item) & ~63ull);
+        if (s.wf_cap_ok) cap_a = std::min(cap_a, s.wf_cap_ok);
+        // counts per (batch, chunk of fs->cap_items items) -> the plan: m consecutive chunks become one, every buffer as long as
+        // the largest group's counts need; the largest m whose buffers fit the steady budget
+        auto make_plan = [&](pt_scene::FrameStats& f) {
+            const uint32_t ca = f.cap_items, lv = f.levels;
+            std::vector<std::vector<uint32_t>> batches;   // slots of each batch, in order
+            for (uint32_t k = 0; k < f.n_slots; ++k) {
+                if (f.first_item_of_slot[k] == 0u) batches.emplace_back();
+                if (batches.empty()) return false;
+                batches.back().push_back(k);
+            }
+            if (batches.empty() || ca == 0) return false;
+            uint32_t m_max = 1;
+            for (auto& bt : batches) m_max = std::max<uint32_t>(m_max, (uint32_t)bt.size());
+            // (PT_WF_CHUNK caps a chunk; a batch that may be one chunk needs no multiple of ca)
+            m_max = std::min<uint32_t>(m_max, (uint64_t)max_items >= items_per_batch ? (uint32_t)((items_per_batch + ca - 1u) / ca) : std::max(1u, max_items / ca));
+            for (uint32_t m = m_max; m >= 1; --m) {
+                uint64_t q1 = 0, q0 = 0, hh = 0, ss = 0, ee = 0;
+                std::vector<uint64_t> tot_q(lv, 0), tot_s(lv, 0);
+                for (auto& bt : batches)
+                    for (size_t g0 = 0; g0 < bt.size(); g0 += m)
+                        for (uint32_t b = 0; b < lv; ++b) {
+                            uint64_t nq = 0, ns = 0, ne = 0;
+                            for (size_t k = g0; k < std::min(bt.size(), g0 + m); ++k) {
+                                const uint32_t* row = f.host + ((size_t)bt[k] * lv + b) * 4;
+                                nq += row[0];
+                                ns += row[1];
+                                ne += row[2];
+                            }
+                            tot_q[b] += nq;
+                            tot_s[b] += ns;
+                            if (b >= 1) {   // (queue b lives in queue[b & 1]; the hits of its casts by queue position)
+                                uint64_t& q = (b & 1u) ? q1 : q0;
+                                q = std::max(q, nq);
+                                hh = std::max(hh, nq);
+                            }
+                            ss = std::max(ss, ns);
+                            ee = std::max(ee, ne);
+                        }
+                const uint64_t items = std::min<uint64_t>((uint64_t)ca * m, items_per_batch);
+                if (!bounce0_fused) {   // the casts of bounce 0 through the arrays by queue position too (hits, draws, exact list by work item)
+                    hh = std::max(hh, items);
+                    ee = std::max(ee, items);
+                }
+                auto pad = [](uint64_t n) { return (std::max<uint64_t>(n, 1024) + 1023) & ~1023ull; };
+                q0 = pad(q0), q1 = pad(q1), hh = pad(hh), ss = pad(ss), ee = pad(ee);
+                const uint64_t bytes = 68u * (q0 + q1) + 20u * hh + (alpha ? 4u * hh : 0u) + (64u + 16u * lights + 4u) * ss + 16u * ee +
+                                       (rng_one_plane ? 16u : 32u) * items;
+                if ((bytes <= (uint64_t)(steady_gib * 1073741824.0) || m == 1) && std::max({q0, q1, hh, ss, ee, items}) < 0xffffffffull) {
+                    f.plan_cap = (uint32_t)items;
+                    f.plan_q[0] = (uint32_t)q0;
+                    f.plan_q[1] = (uint32_t)q1;
+                    f.plan_h = (uint32_t)hh;
+                    f.plan_s = (uint32_t)ss;
+                    f.plan_e = (uint32_t)ee;
+                    // shadow casts inside the shade kernel where (nearly) every ray of a bounce reaches a lit surface
+                    // (PT_OG_INLINE_ALL=1 in the closed room: +6.6 %; in an open scene: -6 %)
+                    f.plan_inline.assign(p.bounces + 2, 0);
+                    if (inline_auto && use_light_grids)
+                        for (uint32_t b = 1; b < lv && b < f.plan_inline.size(); ++b) f.plan_inline[b] = tot_q[b] > 0 && tot_s[b] * 10 >= tot_q[b] * 6;
+                    f.plan_fresh = true;
+                    if (const char* e = getenv("PT_PLAN_DEBUG"); e && *e && atoi(e)) {
+                        fprintf(stderr, "[ptgpu] frame plan: %u chunks of %u -> 1 of %llu items; queues %llu / %llu, hits %llu, shadow %llu, exact %llu records; %.3f GiB\n",
+                                m, ca, (unsigned long long)items, (unsigned long long)q0, (unsigned long long)q1, (unsigned long long)hh,
+                                (unsigned long long)ss, (unsigned long long)ee, bytes / 1073741824.0);
+                        for (uint32_t b = 0; b < lv; ++b)
+                            fprintf(stderr, "[ptgpu]   bounce %u: %llu rays, %llu shadow records%s\n", b, (unsigned long long)tot_q[b],
+                                    (unsigned long long)tot_s[b], b < f.plan_inline.size() && f.plan_inline[b] ? " (inline)" : "");
+                    }
+                    return true;
+                }
+            }
+            return false;
+        };
+        if (!graphs_on) {
+            auto& slot = s.frame_stats[stat_key];
+            if (!slot) {
+                if (s.frame_stats.size() > 64) {   // (a caller cycling through configurations: start over)
+                    HIP_CHECK(hipDeviceSynchronize());
+                    s.frame_stats.clear();
+                }
+                s.frame_stats[stat_key] = std::make_unique<pt_scene::FrameStats>();
+            }
+            fs = s.frame_stats[stat_key].get();
+            if (fs->pending) {
+                const hipError_t q = hipEventQuery(fs->done);
+                (void)hipGetLastError();   // (hipErrorNotReady is no error)
+                if (q == hipSuccess) {
+                    fs->pending = false;
+                    bool overflow = false;
+                    for (uint32_t k = 0; k < fs->n_slots; ++k) overflow = overflow || fs->host[(size_t)k * fs->levels * 4 + 3] != 0u;
+                    if (overflow) {
+                        // cannot happen (the counts of a configuration do not change): a queue sized from them ran full
+                        fs->valid = fs->planned = false;
+                        fail(PT_ERR_DEVICE, "internal error: a path queue sized from an earlier frame's counts ran full; the previous frame of "
+                                            "this configuration is not to be trusted");
+                    }
+                    if (!fs->planned) {
+                        fs->valid = true;
+                        fs->planned = make_plan(*fs);
+                    }
+                }
+            }
+        }
+        bool exact = fs && fs->planned && !fs->plan_failed;
+        if (exact) {
+            cap = fs->plan_cap;
+            cap_q[0] = fs->plan_q[0], cap_q[1] = fs->plan_q[1], cap_h = fs->plan_h, cap_s = fs->plan_s, cap_e = fs->plan_e;
+            inline_at = fs->plan_inline;
+            inline_at.resize(p.bounces + 2, 0);
+        }
+        if (!exact) {
+            cap = cap_a;
+            cap_q[0] = cap_q[1] = cap_h = cap_s = cap_e = cap;
+        }
+        // allocation; a device that cannot provide the buffers (shared GPU) gets half-size chunks with every queue as long as
+        // the chunk, and so on, down to 1 Mi items
+        const bool give_back = exact && fs->plan_fresh;   // (a new plan gives memory back, once)
+        auto fit = [give_back](DeviceBuffer& b, size_t n) {
+            if (give_back && b.bytes > n + n / 4 + (64u << 20)) b.release();
+            return b.try_ensure(n);
+        };
         while (true) {
             multi_chunk = (uint64_t)cap < items_per_batch;
-            const size_t lights = std::max(1u, s.dev.n_lights);
-            bool ok = w.queue[0].try_ensure((size_t)cap * 68u) && w.queue[1].try_ensure((size_t)cap * 68u) &&   // (64 B + the entry word)
-                      w.hits.try_ensure((size_t)cap * 20u) && w.shadow.try_ensure((size_t)cap * 64u) &&
-                      w.contrib.try_ensure((size_t)cap * 16u * lights) && w.rng[0].try_ensure((size_t)cap * 32u) &&
-                      (!(multi_chunk && wf_overlap) || w.rng[1].try_ensure((size_t)cap * 32u)) &&
-                      (!alpha || w.draws.try_ensure((size_t)cap * 4u)) &&   // RNG draw index of the alpha walk
-                      w.offgrid.try_ensure((size_t)cap * 4u) &&   // shadow jobs left to k_og_shadow_offgrid (long normals; rays the wavefront walker does not take)
-                      w.exact[0].try_ensure((size_t)cap * 8u) && w.exact[1].try_ensure((size_t)cap * 8u) &&   // casts left to k_wf_trace_exact: queue index + hit word
-                                                                                                        // (wf_exact_words), one list per bounce parity
+            const bool two_rng = !rng_one_plane && multi_chunk && wf_overlap;
+            bool ok = fit(w.queue[0], (size_t)cap_q[0] * 68u) && fit(w.queue[1], (size_t)cap_q[1] * 68u) &&   // (64 B + the entry word)
+                      fit(w.hits, (size_t)cap_h * 20u) && fit(w.shadow, (size_t)cap_s * 64u) &&
+                      fit(w.contrib, (size_t)cap_s * 16u * lights) && fit(w.rng[0], (size_t)cap * (rng_one_plane ? 16u : 32u)) &&
+                      (!two_rng || fit(w.rng[1], (size_t)cap * 32u)) &&
+                      (!alpha || fit(w.draws, (size_t)cap_h * 4u)) &&   // RNG draw index of the alpha walk
+                      fit(w.offgrid, (size_t)cap_s * 4u) &&   // shadow jobs left to k_og_shadow_offgrid (long normals; rays the wavefront walker does not take)
+                      fit(w.exact[0], (size_t)cap_e * 8u) && fit(w.exact[1], (size_t)cap_e * 8u) &&   // casts left to k_wf_trace_exact: queue index + hit word
+                      (!bounce0_fused || w.block_mask.try_ensure((size_t)blocks64 * 4u + 4u + tm.n_local)) &&
                       // casts left to k_wf_trace_wide: at most one per lane in flight when the queue runs dry
                       // (4 B the queue index + 20 B a hit + 4 B the progress of the walk: wf_list_* in pt_wavefront.h)
-                      (!bounce0_fused || w.block_mask.try_ensure((size_t)blocks64 * 4u + 4u + tm.n_local)) &&
                       (!wf_defer ||
-                       w.deferred.try_ensure((wf_allwide && !alpha ? (size_t)cap : (size_t)s.trace_blocks * WF_THREADS) * 4u *
+                       w.deferred.try_ensure((wf_allwide && !alpha ? (size_t)std::max(cap_q[0], cap_q[1]) : (size_t)s.trace_blocks * WF_THREADS) * 4u *
                                              (alpha ? WF_LIST_WORDS_ALPHA : WF_LIST_WORDS_OPAQUE)));
             if (ok) {
-                if (multi_chunk) s.wf_cap_ok = cap;   // (a frame that fits in one chunk says nothing about larger ones)
+                if (exact) fs->plan_fresh = false;
                 break;
             }
             for (DeviceBuffer* b : {&w.queue[0], &w.queue[1], &w.hits, &w.shadow, &w.contrib, &w.rng[0], &w.rng[1], &w.draws, &w.offgrid, &w.deferred, &w.exact[0], &w.exact[1], &w.block_mask})
                 b->release();
-            if (cap <= (1u << 20))
-                fail(PT_ERR_DEVICE, "out of device memory: the path queues need %zu bytes for %u work items",
-                     (size_t)cap * (240u + 16u * lights), cap);
-            cap = std::max<uint32_t>(1u << 20, (cap / 2u) & ~63u);
+            if (exact) {   // (no room for the planned sizes: as a first frame)
+                exact = false;
+                fs->plan_failed = true;
+                cap = cap_a;
+            } else {
+                if (cap <= (1u << 20))
+                    fail(PT_ERR_DEVICE, "out of device memory: the path queues need %zu bytes for %u work items", (size_t)cap * per_item, cap);
+                cap = std::max<uint32_t>(1u << 20, (cap / 2u) & ~63u);
+                s.wf_cap_ok = cap;
+            }
+            cap_q[0] = cap_q[1] = cap_h = cap_s = cap_e = cap;
+            std::fill(inline_at.begin(), inline_at.end(), 0);
         }
-        if (multi_chunk && wf_overlap) {
+        s.queue_bytes_last = w.queue[0].bytes + w.queue[1].bytes + w.hits.bytes + w.shadow.bytes + w.contrib.bytes + w.rng[0].bytes +
+                             w.rng[1].bytes + w.draws.bytes + w.offgrid.bytes + w.exact[0].bytes + w.exact[1].bytes + w.deferred.bytes;
+        s.queue_chunk_last = cap;
+        s.frame_planned_last = exact ? 1u : 0u;
+        if (fs) {
+            // this frame's counts, one line per (batch, chunk): taken every frame (a few KB) - the first frame's feed the plan,
+            // the later ones only say whether a queue ran full
+            const uint32_t n_batches = (p.samples + batch - 1u) / batch;
+            stats_slots = 0;
+            for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
+                const uint64_t tot = (uint64_t)blocks64 * 64u * std::min(batch, p.samples - s0);
+                stats_slots += (uint32_t)((tot + cap - 1u) / cap);
+            }
+            (void)n_batches;
+            if (!fs->pending) {
+                if (fs->n_slots != stats_slots || fs->levels != levels || !fs->host) {
+                    if (fs->host) (void)hipHostFree(fs->host);
+                    fs->host = nullptr;
+                    HIP_CHECK(hipHostMalloc((void**)&fs->host, (size_t)stats_slots * levels * 16u));
+                    fs->n_slots = stats_slots;
+                    fs->levels = levels;
+                }
+                if (!fs->done) HIP_CHECK(hipEventCreateWithFlags(&fs->done, hipEventDisableTiming));
+                fs->cap_items = cap;
+                fs->first_item_of_slot.assign(stats_slots, 0u);
+                s.stats_dev.ensure((size_t)stats_slots * levels * 16u);
+            } else {
+                stats_slots = 0;   // (an earlier frame's line is still on its way)
+            }
+        }
+        // (only the pipelines with a k_wf_rng launch: a FIFTH stream - the caller's, shadow, wide, exact and this one - makes two
+        // of them share one of the device's four hardware queues (ROCm's default), and every launch of the frame then waits
+        // ~45 us longer for its turn: config 3, 40.3 -> 41.8 ms a frame with the stream merely existing)
+        if (multi_chunk && wf_overlap && !rng_one_plane) {
             if (!w.side_rng) {
                 HIP_CHECK(hipStreamCreateWithFlags(&w.side_rng, hipStreamNonBlocking));
                 HIP_CHECK(hipEventCreateWithFlags(&w.ev_rng, hipEventDisableTiming));
@@ -1720,7 +1938,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     if (wf_graph && mode == 2 && !timing && !counting && !exit_times && !o.progress && !(allow_preview && o.preview)) {
         const pt_scene::WfPipe& w = s.pipe;
         graph_key = {p.width, p.height, p.samples, p.bounces, (uint64_t)p.tonemap, o.flags, o.shard_rank, o.shard_count, o.tile_w,
-                     o.tile_h, o.sample_batch, (uint64_t)d_rgb8, (uint64_t)accum, (uint64_t)d_tiles, cap, batch,
+                     o.tile_h, o.sample_batch, (uint64_t)d_rgb8, (uint64_t)accum, (uint64_t)d_tiles, cap, cap_q[0], cap_q[1], cap_h, cap_s, cap_e, batch,
                      (uint64_t)s.staging_buf.p, (uint64_t)w.queue[0].p, (uint64_t)w.queue[1].p, (uint64_t)w.hits.p,
                      (uint64_t)w.shadow.p, (uint64_t)w.contrib.p, (uint64_t)w.ctr.p, (uint64_t)w.rng[0].p, (uint64_t)w.rng[1].p,
                      (uint64_t)w.draws.p, (uint64_t)w.offgrid.p, (uint64_t)w.deferred.p, (uint64_t)w.exact[0].p, (uint64_t)w.exact[1].p, (uint64_t)s.trace_blocks,
@@ -1755,6 +1973,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         block_empty = (const uint32_t*)s.pipe.block_mask.p;
     }
     s.last_mask_blocks = block_empty ? blocks64 : 0u;
+    uint32_t stats_line = 0;
     for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
         P.sample_begin = s0;
         P.sample_end = std::min(p.samples, s0 + batch);
@@ -1778,11 +1997,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             // chunk c runs its bounces (k_wf_rng is pure integer ALU work; the traversal kernels leave ~40 % of
             // the issue slots idle and end in a drain phase)
             // both kinds of grid: the bounce-0 kernel computes the ChaCha block itself (GRID 3)
-            static const bool fuse_rng = [] {
-                const char* e = getenv("PT_OG_FUSE_RNG");
-                return e && *e ? atoi(e) != 0 : true;
-            }();
-            const bool fused_rng = fuse_rng && bounce0_fused;
+            const bool fused_rng = rng_one_plane;   // (PT_OG_FUSE_RNG=0: off)
             const bool rng_ahead = !fused_rng && wf_overlap && total_items > cap && pipe.side_rng != nullptr;
             uint32_t chunk_no = 0;
             for (uint32_t base = 0; base < total_items; base += cap, ++chunk_no) {
@@ -1791,6 +2006,12 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 W.item_base = base;
                 W.n_items = std::min(cap, total_items - base);
                 W.cap = cap;
+                W.hcap = cap_h;
+                W.scap = cap_s;
+                W.ecap = cap_e;
+                W.qcap_in = cap_q[0];
+                W.qcap_out = cap_q[1];
+                W.rng_first_plane = rng_one_plane ? 1u : 0u;
                 W.n_mask_blocks = blocks64;
                 uint4* rng_planes = (uint4*)pipe.rng[rng_ahead ? (chunk_no & 1u) : 0u].p;
                 // coherence sorting of the survivors by direction octant: measured (MI355X, config 3) trace of bounce 1
@@ -1845,6 +2066,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 }
                 for (uint32_t b = 0; b <= p.bounces; ++b) {
                     W.bounce = b;
+                    W.qcap_in = cap_q[b & 1u];          // (queue b lives in pipe.queue[b & 1])
+                    W.qcap_out = cap_q[(b + 1u) & 1u];
                     W.walk_steps = wf_walk ? wf_walk : (b == 0 ? 20u : 12u);
                     float4* q_in = (float4*)pipe.queue[b & 1].p;
                     float4* q_out = (float4*)pipe.queue[(b + 1) & 1].p;
@@ -1856,7 +2079,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                         const char* e = getenv("PT_OG_INLINE_ALL");
                         return e && *e ? atoi(e) : 0;
                     }();
-                    const int grid_mode = (prim && bounce0_fused) ? (fused_rng ? 3 : 2) : (use_light_grids && inline_later ? 1 : 0);
+                    // (... or where the frame plan found (nearly) every ray of the bounce reaching a lit surface)
+                    const int grid_mode = (prim && bounce0_fused) ? (fused_rng ? 3 : 2)
+                                                                  : (use_light_grids && (inline_later || (b < inline_at.size() && inline_at[b])) ? 1 : 0);
 #define PT_LAUNCH_ACP(kernel, grid, threads, ...)                                                                                      \
     do {                                                                                                                               \
         if (prim && alpha && counting)                                                                                                  \
@@ -1929,7 +2154,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             const bool allwide = wf_allwide && !alpha && W.defer_age != 0u;
                             if (allwide) {
                                 split_shade = false;
-                                W.list_cap = cap;
+                                W.list_cap = std::max(cap_q[0], cap_q[1]);
                                 W.split_deferred = 0u;
                             }
                             // The casts the wavefront walker does not take (slack_is_capped): one lane each on the grown-box walker.
@@ -1977,7 +2202,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             }
                             if (allwide) {
                                 hipLaunchKernelGGL(k_wf_list_identity, dim3((uint32_t)s.n_cu * 8u), dim3(256), 0, st_main,
-                                                   (uint32_t*)pipe.deferred.p, cap, wctr, b);
+                                                   (uint32_t*)pipe.deferred.p, W.list_cap, wctr, b);
                                 HIP_CHECK(hipGetLastError());
                             } else {
                                 PT_LAUNCH_ACP(k_wf_trace, s.trace_blocks, WF_THREADS, dev, W, d_tiles, q_in, (uint4*)pipe.hits.p,
@@ -2128,6 +2353,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 // the next chunk clears the counters and reuses the queues, accumulate reads the staging area:
                 // join the side stream
                 if (st_shadow != st_main) HIP_CHECK(hipStreamWaitEvent(st_main, pipe.ev_shadow, 0));
+                if (fs && stats_slots && stats_line < stats_slots) {   // this chunk's counts: one line of the frame's statistics
+                    hipLaunchKernelGGL(k_wf_stats, dim3(1), dim3(64u * ((p.bounces + 3u + 63u) / 64u)), 0, st_main, (const WfCounters*)wctr,
+                                       p.bounces + 3u, (uint32_t*)s.stats_dev.p + (size_t)stats_line * (p.bounces + 3u) * 4u);
+                    HIP_CHECK(hipGetLastError());
+                    fs->first_item_of_slot[stats_line] = base;
+                    ++stats_line;
+                }
             }
         }
         if (mode >= 1) {
@@ -2153,6 +2385,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             HIP_CHECK(hipStreamSynchronize(stream));
             o.progress(P.sample_end, p.samples, o.progress_user);
         }
+    }
+    if (fs && stats_slots && stats_line == stats_slots) {   // the frame's counts on their way to the host (read when the next frame is planned)
+        HIP_CHECK(hipMemcpyAsync(fs->host, s.stats_dev.p, (size_t)stats_slots * (p.bounces + 3u) * 16u, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipEventRecord(fs->done, stream));
+        fs->pending = true;
     }
     const size_t ev_post = ev;
     if (timing) HIP_CHECK(hipEventRecord(get_event(s, ev++), stream));
@@ -2604,6 +2841,9 @@ int pt_get_cull_stats(const pt_scene* scene, uint32_t* n_blocks, uint32_t* n_emp
 int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out) {
     if (!scene || !out) return PT_ERR_INVALID;
     *out = scene->info;
+    out->queue_bytes = scene->queue_bytes_last;
+    out->queue_chunk_items = scene->queue_chunk_last;
+    out->frame_planned = scene->frame_planned_last;
     return PT_OK;
 }
 
@@ -2661,7 +2901,7 @@ int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint
         Staged<uint32_t> d_def(nullptr, (size_t)blocks * WF_THREADS * 7);   // (index | carried hit | progress: wf_list_*)
         WfParams W{};
         W.n_items = (uint32_t)n;
-        W.cap = cap;
+        W.cap = W.qcap_in = W.qcap_out = W.hcap = W.scap = W.ecap = cap;
         W.bounce = 1;
         W.refill_min = 16;
         W.walk_steps = 12;

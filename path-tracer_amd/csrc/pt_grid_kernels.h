@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_og_primary(DevScene S, WfParams W, cons
             }
         }
     }
-    wf_store_hit(hits, W.cap, i, best, hit);
+    wf_store_hit(hits, W.hcap, i, best, hit);
     if (ALPHA) draws[i] = draw;
     if (COUNT) {
         atomicAdd(&gctr->segments, (unsigned long long)lc.segments);
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, (!ALPHA && !COUNT && !DIRL) ? 8 : 1) void k_og
                                                    const float4* __restrict__ contrib, float4* __restrict__ queue_next,
                                                    float* __restrict__ staging, uint32_t* __restrict__ offgrid,
                                                    WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
-    const uint32_t n = ctr[W.bounce].shadow_count;
+    const uint32_t n = min(ctr[W.bounce].shadow_count, W.scap);
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     uint32_t n_skipped = 0;
     for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += gridDim.x * 256u) {
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, (!ALPHA && !COUNT && !DIRL) ? 8 : 1) void k_og
             continue;
         }
         for (uint32_t li = 0; li < S.n_lights; ++li) {
-            const float4 c = contrib[(size_t)li * W.cap + idx];
+            const float4 c = contrib[(size_t)li * W.scap + idx];
             const f3 term = mk3(c.x, c.y, c.z);
             if (S.n_lights > 1 && wf_light_is_moot(S.lights[li], term, pos)) {   // (a single light was already filtered by k_wf_shade)
                 if (COUNT) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, (!ALPHA && !COUNT && !DIRL) ? 8 : 1) void k_og
             const f3 rad = og_light_radiance<ALPHA, COUNT, DIRL>(S, li, pos, gn, uv, sphere, lc);
             if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) color = color + mul_ew(term, rad);
         }
-        og_retire(color, __float_as_uint(s2.w), __float_as_uint(s3.x), queue_next, W.cap, staging);
+        og_retire(color, __float_as_uint(s2.w), __float_as_uint(s3.x), queue_next, W.qcap_out, staging);
     }
     if (COUNT) {
         atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_og_shadow_offgrid(DevScene S, WfParams 
                                                            float4* __restrict__ queue_next, float* __restrict__ staging,
                                                            const uint32_t* __restrict__ offgrid,
                                                            WfCounters* __restrict__ ctr, DevCounters* __restrict__ gctr) {
-    const uint32_t n = LIST ? ctr[W.bounce].offgrid_count : ctr[W.bounce].shadow_count;
+    const uint32_t n = min(LIST ? ctr[W.bounce].offgrid_count : ctr[W.bounce].shadow_count, W.scap);
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     uint32_t n_skipped = 0;
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_og_shadow_offgrid(DevScene S, WfParams 
         f3 color = mk3(s2.x, s2.y, s2.z);
         for (uint32_t li = LIST ? __float_as_uint(s3.z) : 0u; li < S.n_lights; ++li) {   // (k_wf_shade writes 0 there)
             const DevLight& L = S.lights[li];
-            const float4 c = contrib[(size_t)li * W.cap + idx];
+            const float4 c = contrib[(size_t)li * W.scap + idx];
             const f3 term = mk3(c.x, c.y, c.z);
             if (S.n_lights > 1 && wf_light_is_moot(L, term, sf.pos)) {   // (a single light was already filtered by k_wf_shade)
                 if (COUNT) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_og_shadow_offgrid(DevScene S, WfParams 
             light_radiance<COUNT, true>(S, L, sf, rad, ldir, lc);
             if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) color = color + mul_ew(term, rad);
         }
-        og_retire(color, __float_as_uint(s2.w), __float_as_uint(s3.x), queue_next, W.cap, staging);
+        og_retire(color, __float_as_uint(s2.w), __float_as_uint(s3.x), queue_next, W.qcap_out, staging);
     }
     if (COUNT) {
         atomicAdd(&gctr->shadow_rays, (unsigned long long)lc.shadow_rays);

@@ -71,7 +71,15 @@ struct WfParams {
     RenderParams P;
     uint32_t item_base;   // first absolute work item of this chunk
     uint32_t n_items;     // items in this chunk
-    uint32_t cap;         // queue capacity (records)
+    uint32_t cap;         // work items per chunk: the stride of the RNG planes (and, when nothing smaller is known, of everything)
+    // capacities of what is indexed by a QUEUE position instead of a work item (the host sizes them by the records that can
+    // exist - a frame's counts are known exactly once it has been rendered once, pt_gpu.hip FramePlan):
+    uint32_t qcap_in;     //   the queue this bounce reads (ray plane, path plane at 2 x qcap_in, entry plane at 4 x qcap_in)
+    uint32_t qcap_out;    //   the queue this bounce writes (the next bounce's)
+    uint32_t hcap;        //   hit records (word plane, then the (key, u, v) plane) and the alpha walk's draw counts
+    uint32_t scap;        //   shadow records, the contrib planes' stride, the off-grid list
+    uint32_t ecap;        //   the exact lists (queue indices, then the words plane)
+    uint32_t rng_first_plane;   // the RNG buffer starts with this plane (1: the fused bounce-0 kernel keeps words 0-3 in registers)
     uint32_t bounce;      // current bounce (shade / shadow)
     uint32_t refill_min;  // idle lanes that trigger a queue refill in the persistent kernels
     uint32_t walk_steps;  // node steps per walking phase
@@ -114,6 +122,7 @@ struct WfCounters {  // one set per bounce level, zeroed once per chunk
     // memory-side atomic unit serialises per line, not per word: eight cursors in one line behaved like one)
     uint32_t trace_work[WF_CURSORS * WF_CURSOR_STRIDE];
     uint32_t shadow_work[WF_CURSORS * WF_CURSOR_STRIDE];
+    uint32_t overflow;       // a kernel found a list full (a capacity of the plan was wrong): the frame is not to be trusted
     uint32_t offgrid_count;  // shadow records k_og_shadow left to k_og_shadow_offgrid (pt_grid_kernels.h)
     uint32_t deferred_count; // casts k_wf_trace left to k_wf_trace_wide in its drain phase
     uint32_t exact_count;    // casts k_wf_trace left to k_wf_trace_exact when it fetched them (slack_is_capped)
@@ -816,13 +825,13 @@ struct WfRng {
     uint32_t block;      // index of the block held in w (0xffffffff = none)
     uint32_t w[16];
 };
-PT_D uint32_t wf_rng_staged(const uint4* __restrict__ planes, uint32_t cap, uint32_t item, uint32_t idx) {
-    const uint32_t* p = (const uint32_t*)(planes + (size_t)(idx >> 2) * cap + item);
+PT_D uint32_t wf_rng_staged(const uint4* __restrict__ planes, uint32_t cap, uint32_t first_plane, uint32_t item, uint32_t idx) {
+    const uint32_t* p = (const uint32_t*)(planes + (size_t)((idx >> 2) - first_plane) * cap + item);
     return p[idx & 3u];
 }
 PT_D float wf_rng_draw(WfRng& fb, const WfParams& W, const uint32_t* __restrict__ tile_offsets,
                        const uint4* __restrict__ planes, uint32_t item, uint32_t idx) {
-    if (idx < WF_RNG_STAGED) return wf_rng_float(wf_rng_staged(planes, W.cap, item, idx));
+    if (idx < WF_RNG_STAGED) return wf_rng_float(wf_rng_staged(planes, W.cap, W.rng_first_plane, item, idx));
     if ((idx >> 4) != fb.block) {
         ItemRef it = decode_item(W.P, tile_offsets, W.item_base + item);
         fb.block = idx >> 4;
@@ -866,7 +875,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
     if (gctr && threadIdx.x == 0 && W.bounce < 8) atomicMin(&gctr->launch_start[W.bounce], __builtin_amdgcn_s_memrealtime());
     unsigned long long t_queue_done = 0;
 #endif
-    const uint32_t n = PRIMARY ? W.n_items : ctr[W.bounce].queue_count;
+    const uint32_t n = PRIMARY ? W.n_items : min(ctr[W.bounce].queue_count, W.qcap_in);   // (beyond the capacity: an overflowed, flagged frame)
     uint32_t* cursor = ctr[W.bounce].trace_work;
     uint32_t ov_node[PT_KD_STACK - WF_LDS_STACK];
     float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
@@ -930,7 +939,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                 hit = true;
             }
             if (WF_LEAN_HIT && !ALPHA && hit) rederive_hit(S, T, best);
-            wf_store_hit(hits, W.cap, idx, best, hit);
+            wf_store_hit(hits, W.hcap, idx, best, hit);
             if (ALPHA) draws[idx] = draw;   // rng.gen() calls of the path so far (the alpha walk may have drawn)
             active = false;
             lstate = WF_LANE_IDLE;
@@ -979,7 +988,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                     // live paths only - items outside the image never leave the bounce-0 kernels)
                     const float4* q = wf_ray_rec(queue, idx);
                     float4 q0 = q[0], q1 = q[1];
-                    entry_word = W.use_entry ? wf_entry_plane(queue, W.cap)[idx] : 0u;
+                    entry_word = W.use_entry ? wf_entry_plane(queue, W.qcap_in)[idx] : 0u;
                     o = mk3(q0.x, q0.y, q0.z);
                     d = mk3(q0.w, q1.x, q1.y);
                     valid_item = true;
@@ -1010,7 +1019,8 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PR
                 uint32_t slot = 0u;
                 if (W.exact_handover == 1u) slot = wf_reserve(&ctr[W.bounce].exact_count, handover);   // (2: k_wf_shade listed it)
                 if (handover) {
-                    if (W.exact_handover == 1u) exact_list[slot] = idx;
+                    if (W.exact_handover == 1u && slot < W.ecap) exact_list[slot] = idx;
+                    else if (W.exact_handover == 1u) ctr[0].overflow = 1u;
                     if (W.split_deferred) ((uint32_t*)hits)[idx] = WF_HIT_PENDING;
                     if (COUNT) lc.segments--;   // counted by k_wf_trace_exact
                     active = false;
@@ -1367,7 +1377,7 @@ __global__ __launch_bounds__(WF_THREADS, WF_MIN_WAVES) void k_wf_trace_wide(DevS
             }
             const bool found = best.pid != 0xffffffffu && best.key == kmin && best.ord == omin;
             const unsigned long long winners = __ballot(found) & group_mask;
-            const uint32_t h_cap = W.split_deferred ? W.list_cap : W.cap, h_idx = W.split_deferred ? e : idx;
+            const uint32_t h_cap = W.split_deferred ? W.list_cap : W.hcap, h_idx = W.split_deferred ? e : idx;
             if (!ALPHA) {
                 if (live) {
                     if (winners) {
@@ -1491,7 +1501,7 @@ __global__ __launch_bounds__(256) void k_wf_trace_exact_coop(DevScene S, WfParam
     static_assert(WF_EXACT_SOFT + PT_KD_STACK + L <= WF_EXACT_CAP, "stack of the exact walker");
     __shared__ uint32_t st_node[GROUPS][WF_EXACT_CAP];
     __shared__ float st_t0[GROUPS][WF_EXACT_CAP], st_t1[GROUPS][WF_EXACT_CAP];
-    const uint32_t n = ctr[W.bounce].exact_count;
+    const uint32_t n = min(ctr[W.bounce].exact_count, W.ecap);
     if (n == 0u) return;
     const uint32_t group = threadIdx.x / L, part = threadIdx.x & (L - 1u), lane = threadIdx.x & 63u;
     const unsigned long long group_mask = ((1ull << L) - 1ull) << (lane & ~(L - 1u));
@@ -1672,10 +1682,10 @@ __global__ __launch_bounds__(256) void k_wf_trace_exact_coop(DevScene S, WfParam
                     if (part == 0u) {
                         if (W.split_deferred) {
                             const uint4 rec = pack_hit(win, hit);
-                            wf_exact_words(exact_list, W.cap)[e] = rec.x;
-                            if (hit) ((uint4*)((uint32_t*)hits + W.cap))[idx] = make_uint4(rec.y, rec.z, rec.w, 0u);
+                            wf_exact_words(exact_list, W.ecap)[e] = rec.x;
+                            if (hit) ((uint4*)((uint32_t*)hits + W.hcap))[idx] = make_uint4(rec.y, rec.z, rec.w, 0u);
                         } else {
-                            wf_store_hit(hits, W.cap, idx, win, hit);
+                            wf_store_hit(hits, W.hcap, idx, win, hit);
                         }
                         if (ALPHA) draws[idx] = draw;
                     }
@@ -1714,7 +1724,7 @@ __global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S,
     __shared__ float s_t0[WF_EXACT_LDS_STACK][WF_EXACT_THREADS], s_t1[WF_EXACT_LDS_STACK][WF_EXACT_THREADS];
     uint32_t ov_node[PT_KD_STACK - WF_EXACT_LDS_STACK];
     float ov_t0[PT_KD_STACK - WF_EXACT_LDS_STACK], ov_t1[PT_KD_STACK - WF_EXACT_LDS_STACK];
-    const uint32_t n = ctr[W.bounce].exact_count, tid = threadIdx.x;
+    const uint32_t n = min(ctr[W.bounce].exact_count, W.ecap), tid = threadIdx.x;
     LocalCtr lc = {0, 0, 0, 0, 0, 0};
     uint32_t n_alpha_draws = 0;
     for (uint32_t e = blockIdx.x * WF_EXACT_THREADS + tid; e < n; e += gridDim.x * WF_EXACT_THREADS) {
@@ -1738,14 +1748,48 @@ __global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S,
         FatRay F;
         float r0 = 0.f, r1 = 0.f;
         const bool in_scene = F.init(S, o, d, 0.f, r0, r1);
-        RawHit best, kept;
+        // The alpha walk (mod.rs:188-205) looks at the sorted hit list entry by entry; a walk per entry - from the origin again, with
+        // the entries already seen filtered out - made a translucent cast of config 5 five walks long.  So one walk collects the
+        // KH nearest entries behind (t_prev, ord_prev), in order, and the list is walked from those; only a ray that skips all
+        // KH of them walks again.  (Opaque scenes: KH = 1, the closest hit.)
+        constexpr int KH = ALPHA ? 4 : 1;
+        RawHit cand[KH], best, kept;
         bool have_kept = false, hit = false;
         float t_prev = -INFINITY;
         uint32_t ord_prev = 0u;
-        while (true) {   // one turn per entry of the sorted hit list the alpha walk looks at (opaque scenes: one)
-            best.key = INFINITY;
-            best.ord = 0xffffffffu;
-            best.pid = 0xffffffffu;
+        best.pid = 0xffffffffu;
+        while (true) {
+            int nc = 0;
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                cand[k].key = INFINITY;
+                cand[k].ord = 0xffffffffu;
+                cand[k].pid = 0xffffffffu;
+            }
+            // a hit (key, ord) behind (t_prev, ord_prev): into the sorted candidates if it is among the KH nearest (a primitive is
+            // referenced from several leaves: the same entry again is not a new one)
+            auto offer = [&](float key, uint32_t ord, uint32_t pid, float u, float v, uint32_t flags) {
+                if (!(key == key) || !key_less(t_prev, ord_prev, key, ord) || !key_less(key, ord, cand[KH - 1].key, cand[KH - 1].ord)) return;
+#pragma unroll
+                for (int k = 0; k < KH; ++k)
+                    if (cand[k].key == key && cand[k].ord == ord) return;
+                RawHit in;
+                in.key = key;
+                in.ord = ord;
+                in.pid = pid;
+                in.u = u;
+                in.v = v;
+                in.flags = flags;
+#pragma unroll
+                for (int k = 0; k < KH; ++k) {   // insertion: `in` moves down to its place, the last candidate falls out
+                    if (key_less(in.key, in.ord, cand[k].key, cand[k].ord)) {
+                        const RawHit t = cand[k];
+                        cand[k] = in;
+                        in = t;
+                    }
+                }
+                if (nc < KH) ++nc;
+            };
             if (in_scene) {
                 int sp = 0;
                 uint32_t node = 0u;
@@ -1790,7 +1834,19 @@ __global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S,
                         for (uint32_t i = 0; i < n_refs; ++i) {
                             float4 q0, q1, q2;
                             load_prim_record(lp + 3 * i, q0, q1, q2);
-                            og_test_closest<COUNT>(o, d, q0, q1, q2, t_prev, ord_prev, best, lc);
+                            const uint32_t pid = __float_as_uint(q0.w);
+                            if (COUNT) lc.tris++;
+                            if (!(pid & PT_PRIM_SPHERE)) {
+                                float dist, u, v;
+                                bool bf;
+                                if (isect_triangle(o, d, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), dist, u, v, bf))
+                                    offer(dist, PT_PRIM_INDEX(pid) * 2u, pid, u, v, bf ? 1u : 0u);
+                            } else {
+                                float ts[2], key[2];
+                                bool ex[2];
+                                const int nh = isect_sphere(o, d, mk3(q0.x, q0.y, q0.z), q1.x, ts, key, ex);
+                                for (int k = 0; k < nh; ++k) offer(key[k], PT_PRIM_INDEX(pid) * 2u + (ex[k] ? 1u : 0u), pid, ts[k], 0.f, 2u | (ex[k] ? 4u : 0u));
+                            }
                         }
                     }
                     if (descend) continue;
@@ -1806,8 +1862,8 @@ __global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S,
                             t0 = ov_t0[sp - WF_EXACT_LDS_STACK];
                             t1 = ov_t1[sp - WF_EXACT_LDS_STACK];
                         }
-                        // (the segment's hits have keys >= t0 * min(1, |d|): beyond the best one it holds nothing of interest)
-                        if (!(t0 * key_scale > best.key + PT_EXIT_ABS)) {
+                        // (the segment's hits have keys >= t0 * min(1, |d|): beyond the last candidate it holds nothing of interest)
+                        if (!(t0 * key_scale > cand[KH - 1].key + PT_EXIT_ABS)) {
                             more = true;
                             break;
                         }
@@ -1815,27 +1871,42 @@ __global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S,
                     if (!more) break;
                 }
             }
-            hit = best.pid != 0xffffffffu;
-            if (hit && !hit_passes_slab(S, o, d)) {   // kdtree-ray's box test: no hits at all
-                hit = false;
+            // kdtree-ray's box test: a ray it rejects has no hits at all
+            if (nc > 0 && !hit_passes_slab(S, o, d)) {
+                nc = 0;
                 have_kept = false;
             }
-            if (!ALPHA || !hit) break;
-            const float opacity = hit_opacity(S, o, d, best);
-            if (COUNT) lc.shaded++;
-            bool stop = opacity >= 1.f;
-            if (!stop && opacity > 0.001f) {
-                WfRng fb;
-                fb.block = 0xffffffffu;
-                stop = wf_rng_draw(fb, W, tile_offsets, rng_planes, item, draw++) < opacity;
-                if (COUNT) n_alpha_draws++;
+            hit = false;
+            bool walk_again = false;
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                if (k < nc && !hit) {
+                    best = cand[k];
+                    bool stop = true;
+                    if (ALPHA) {
+                        const float opacity = hit_opacity(S, o, d, best);
+                        if (COUNT) lc.shaded++;
+                        stop = opacity >= 1.f;
+                        if (!stop && opacity > 0.001f) {
+                            WfRng fb;
+                            fb.block = 0xffffffffu;
+                            stop = wf_rng_draw(fb, W, tile_offsets, rng_planes, item, draw++) < opacity;
+                            if (COUNT) n_alpha_draws++;
+                        }
+                    }
+                    if (stop) {
+                        hit = true;
+                    } else {   // skipped: remember it, look at the next entry of the sorted list
+                        kept = best;
+                        have_kept = true;
+                        t_prev = best.key;
+                        ord_prev = best.ord;
+                        if (COUNT) lc.restarts++;
+                        if (k == KH - 1) walk_again = true;   // (all KH candidates skipped: there may be more behind them)
+                    }
+                }
             }
-            if (stop) break;
-            kept = best;   // skipped: remember it, look for the next entry of the sorted list (from the origin again: these are
-            have_kept = true;   // the rare rays, and "behind t_prev" needs no slack argument this way)
-            t_prev = best.key;
-            ord_prev = best.ord;
-            if (COUNT) lc.restarts++;
+            if (!walk_again) break;
         }
         if (ALPHA && !hit && have_kept) {   // every hit skipped: the last one is shaded
             best = kept;
@@ -1843,10 +1914,10 @@ __global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S,
         }
         if (W.split_deferred) {
             const uint4 rec = pack_hit(best, hit);
-            wf_exact_words(exact_list, W.cap)[e] = rec.x;
-            if (hit) ((uint4*)((uint32_t*)hits + W.cap))[idx] = make_uint4(rec.y, rec.z, rec.w, 0u);
+            wf_exact_words(exact_list, W.ecap)[e] = rec.x;
+            if (hit) ((uint4*)((uint32_t*)hits + W.hcap))[idx] = make_uint4(rec.y, rec.z, rec.w, 0u);
         } else {
-            wf_store_hit(hits, W.cap, idx, best, hit);
+            wf_store_hit(hits, W.hcap, idx, best, hit);
         }
         if (ALPHA) draws[idx] = draw;
     }
@@ -1934,18 +2005,18 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
     static_assert(GRID < 2 || PRIMARY, "the camera grid serves bounce 0");
     const bool list_pass = !PRIMARY && index_list != nullptr;
     const uint32_t n_def = list_pass ? ctr[W.bounce].deferred_count : 0u;
-    const uint32_t n = PRIMARY ? W.n_items : list_pass ? n_def + (exact_list ? ctr[W.bounce].exact_count : 0u) : ctr[W.bounce].queue_count;
+    const uint32_t n = PRIMARY ? W.n_items : list_pass ? n_def + (exact_list ? min(ctr[W.bounce].exact_count, W.ecap) : 0u) : min(ctr[W.bounce].queue_count, W.qcap_in);
     // entry e of this launch: its queue record, the word of its hit, the hit
     auto entry_index = [&](uint32_t e) -> uint32_t { return !list_pass ? e : e < n_def ? index_list[e] : exact_list[e - n_def]; };
     auto entry_word = [&](uint32_t e) -> uint32_t {
-        return (!list_pass || e < n_def) ? wf_hit_word(hits, e) : wf_exact_words(exact_list, W.cap)[e - n_def];
+        return (!list_pass || e < n_def) ? wf_hit_word(hits, e) : wf_exact_words(exact_list, W.ecap)[e - n_def];
     };
     auto entry_hit = [&](uint32_t e, uint32_t i, RawHit& h) -> bool {
-        if (!list_pass) return wf_load_hit(hits, W.cap, e, h);
+        if (!list_pass) return wf_load_hit(hits, W.hcap, e, h);
         if (e < n_def) return wf_load_hit(hits, W.list_cap, e, h);
-        const uint32_t x = wf_exact_words(exact_list, W.cap)[e - n_def];
+        const uint32_t x = wf_exact_words(exact_list, W.ecap)[e - n_def];
         if (x == 0xffffffffu) return false;
-        const uint4 k = ((const uint4*)((const uint32_t*)chunk_hits + W.cap))[i];
+        const uint4 k = ((const uint4*)((const uint32_t*)chunk_hits + W.hcap))[i];
         return unpack_hit(make_uint4(x, k.x, k.y, k.z), h);
     };
     uint32_t n_draws = 0, n_new = 0, n_moot = 0, n_hits = 0, n_cam_tris = 0, n_masked = 0;
@@ -2033,7 +2104,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
                 if (COUNT) n_cam_tris += lc.tris - tris_before;
             } else {
                 draw = ALPHA ? draws[i] : 2u;   // 2 = the pixel jitter (+ the draws of the alpha walk)
-                hit = wf_load_hit(hits, W.cap, i, h);
+                hit = wf_load_hit(hits, W.hcap, i, h);
                 if (hit) {  // (a missed cast only adds the background: no ray, no normalisation)
                     const uint2 sc = *(const uint2*)(rng_planes + i);  // jittered screen position (k_wf_rng)
                     primary_from_screen(S, __uint_as_float(sc.x), __uint_as_float(sc.y), o, d);
@@ -2044,7 +2115,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
     }
     if (!PRIMARY && live) {
         const float4* qr = wf_ray_rec(queue_in, i);
-        const float4* qp = wf_path_rec(queue_in, W.cap, i);
+        const float4* qp = wf_path_rec(queue_in, W.qcap_in, i);
         float4 q0 = qr[0], q1 = qr[1], q2 = qp[0], q3 = qp[1];
         o = mk3(q0.x, q0.y, q0.z);
         d = mk3(q0.w, q1.x, q1.y);
@@ -2192,22 +2263,30 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
     }
     if (W.sort_octants & 1u) next_idx = sh_base[0] + sh_oct_off[oct][wave] + oct_rank;
     __syncthreads();  // sh_cnt / sh_base are rewritten by the next step
-    if (GRID == 3 && survive) rng_planes_out[(size_t)W.cap + item] = later_words;   // draws 4-7 of the path
+    // (the queues are sized by the records this very frame is known to produce, pt_gpu.hip FramePlan: a record beyond its
+    // queue's end means that knowledge was wrong - nothing is written, the frame is flagged and rendered again with room)
+    if ((survive && next_idx >= W.qcap_out) || (to_shadow && sh_idx >= W.scap)) {
+        ctr[0].overflow = 1u;
+        survive = false;
+        to_shadow = false;
+    }
+    if (GRID == 3 && survive) rng_planes_out[(size_t)(1u - W.rng_first_plane) * W.cap + item] = later_words;   // draws 4-7 of the path
     if (W.exact_shade_lists) {   // (wave-uniform; 0.24 % of random directions)
         const bool listed = survive && slack_is_capped(__builtin_amdgcn_rcpf(next_d.x), __builtin_amdgcn_rcpf(next_d.y), __builtin_amdgcn_rcpf(next_d.z));
         if (wf_any(listed)) {
             const uint32_t slot = wf_reserve(&ctr[bounce + 1].exact_count, listed);
-            if (listed) exact_next[slot] = next_idx;
+            if (listed && slot < W.ecap) exact_next[slot] = next_idx;
+            else if (listed) ctr[0].overflow = 1u;
         }
     }
     if (survive) {
         float4* qr = wf_ray_rec(queue_out, next_idx);
-        float4* qp = wf_path_rec(queue_out, W.cap, next_idx);
+        float4* qp = wf_path_rec(queue_out, W.qcap_out, next_idx);
         qr[0] = make_float4(next_o.x, next_o.y, next_o.z, next_d.x);
         qr[1] = make_float4(next_d.y, next_d.z, __uint_as_float(item), __uint_as_float((draw & 0xffffu) | ((bounce + 1) << 16)));
         qp[0] = make_float4(next_thr.x, next_thr.y, next_thr.z, __uint_as_float(out_slot));
         qp[1] = make_float4(color.x, color.y, color.z, 0.f);  // colour is patched by the shadow kernels
-        if (W.use_entry) wf_entry_plane(queue_out, W.cap)[next_idx] = S.prim_entry[PT_PRIM_INDEX(h.pid)];
+        if (W.use_entry) wf_entry_plane(queue_out, W.qcap_out)[next_idx] = S.prim_entry[PT_PRIM_INDEX(h.pid)];
     }
     if (to_shadow) {
         float4* sq = shadow_q + (size_t)sh_idx * 4;
@@ -2220,7 +2299,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
             const DevLight& L = S.lights[li];
             f3 ldir = L.kind == PT_LIGHT_POINT ? normalize3(surf.pos - ld3(L.vec)) : ld3(L.vec);
             f3 c = mul_ew(thr, ct_eval_direct(brdf, normal, view, -1.f * ldir));
-            contrib[(size_t)li * W.cap + sh_idx] = make_float4(c.x, c.y, c.z, 0.f);
+            contrib[(size_t)li * W.scap + sh_idx] = make_float4(c.x, c.y, c.z, 0.f);
         }
     } else if (live && hit && !survive) {  // no light can contribute and the path ends: the sample is complete
         float* out = staging + (size_t)out_slot * 3;
@@ -2280,7 +2359,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, GRIDX ? (ALPHA ? WF_SHADE_GRID_WA
                 if (word != WF_HIT_PENDING) {
                     is_hit = word != 0xffffffffu;
                     if (!is_hit) {
-                        const float4* qp = wf_path_rec(queue_in, W.cap, i);
+                        const float4* qp = wf_path_rec(queue_in, W.qcap_in, i);
                         const float4 q2 = qp[0], q3 = qp[1];
                         const uint32_t slot = __float_as_uint(q2.w);
                         if (slot != 0xffffffffu) {
@@ -2383,7 +2462,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
     __shared__ unsigned long long lds_stack[WF_LDS_STACK * WF_THREADS];
     __shared__ unsigned long long lds_top[WF_LDS_NODES ? WF_LDS_NODES : 1];
     wf_load_tree_top(S, lds_top);
-    const uint32_t n = ctr[W.bounce].shadow_count;
+    const uint32_t n = min(ctr[W.bounce].shadow_count, W.scap);
     uint32_t* cursor = ctr[W.bounce].shadow_work;
     uint32_t ov_node[PT_KD_STACK - WF_LDS_STACK];
     float ov_tmax[PT_KD_STACK - WF_LDS_STACK];
@@ -2408,7 +2487,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
 
     auto add_light = [&]() {  // visibility known: add the light (mod.rs:251-261)
         if (!(rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) {
-            float4 c = contrib[(size_t)li * W.cap + idx];
+            float4 c = contrib[(size_t)li * W.scap + idx];
             color = color + mul_ew(mk3(c.x, c.y, c.z), rad);
         }
         ++li;
@@ -2418,7 +2497,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
         while (li < S.n_lights) {
             const DevLight& L = S.lights[li];
             if (S.n_lights > 1) {  // (a single light was already filtered by k_wf_shade)
-                float4 c = contrib[(size_t)li * W.cap + idx];
+                float4 c = contrib[(size_t)li * W.scap + idx];
                 if (wf_light_is_moot(L, mk3(c.x, c.y, c.z), pos)) {
                     if (COUNT) {
                         lc.shadow_rays++;
@@ -2473,7 +2552,7 @@ __global__ __launch_bounds__(WF_THREADS, (!COUNT && !ALPHA) ? WF_PRIMARY_WAVES :
             out[1] = color.y;
             out[2] = color.z;
         } else {
-            wf_path_rec(queue_next, W.cap, next_idx)[1] = make_float4(color.x, color.y, color.z, 0.f);
+            wf_path_rec(queue_next, W.qcap_out, next_idx)[1] = make_float4(color.x, color.y, color.z, 0.f);
         }
         active = false;
     };
