@@ -507,7 +507,7 @@ struct pt_scene {
     // beside the trace of bounce b+1, so the tail of one persistent launch is filled by the other's head.
     struct WfPipe {
         DeviceBuffer queue[2], hits, shadow, contrib, ctr, rng[2], draws, offgrid, deferred, exact[2], block_mask;
-        hipStream_t side = nullptr, side_rng = nullptr, side_wide = nullptr, side_exact = nullptr;
+        hipStream_t side = nullptr, side_wide = nullptr, side_exact = nullptr;
         hipEvent_t ev_shade = nullptr, ev_shadow = nullptr, ev_rng = nullptr, ev_chunk = nullptr, ev_trace = nullptr, ev_wide = nullptr,
                    ev_exact = nullptr, ev_exact_go = nullptr;
     };
@@ -560,7 +560,6 @@ struct pt_scene {
             if (e) (void)hipEventDestroy(e);
         if (pipe.side_exact) (void)hipStreamDestroy(pipe.side_exact);
         if (pipe.side) (void)hipStreamDestroy(pipe.side);
-        if (pipe.side_rng) (void)hipStreamDestroy(pipe.side_rng);
         if (pipe.side_wide) (void)hipStreamDestroy(pipe.side_wide);
     }
     template <class T>
@@ -1668,8 +1667,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         // 64 B (+ the entry word), 20 B hit, 64 B shadow record + 16 B per light, the RNG plane(s), draws, off-grid and exact lists.
         const uint64_t per_item = 68u * 2u + 20u + 64u + 16u * lights + (rng_one_plane ? 16u : 32u) + (alpha ? 4u : 0u) + 4u + 16u;
         // (read per frame: the tests change them)
-        const double first_gib = [] { const char* e = getenv("PT_QUEUE_GIB"); return e && *e ? atof(e) : 16.0; }();
-        const double steady_gib = [first_gib] { const char* e = getenv("PT_QUEUE_STEADY_GIB"); return e && *e ? atof(e) : first_gib; }();
+        // First frame 8 GiB: what the CLI pays for in allocation time (path-tracer render of the 500 k-triangle scene, 1080p x 128 spp,
+        // render_s with 2 / 4 / 8 / 16 / 64 GiB: 0.121 / 0.095 / 0.080 / 0.136-0.29 / 1.69 s - the frame itself is 0.04-0.05 s).
+        // Later frames 16 GiB: config 3 in one pass (13.8 GiB), the closed room in 5 (32 GiB: 3 passes, 1.7 % faster).
+        const double first_gib = [] { const char* e = getenv("PT_QUEUE_GIB"); return e && *e ? atof(e) : 8.0; }();
+        const double steady_gib = [first_gib] { const char* e = getenv("PT_QUEUE_STEADY_GIB"); return e && *e ? atof(e) : std::max(first_gib, 16.0); }();
         static const bool inline_auto = [] { const char* e = getenv("PT_OG_INLINE_AUTO"); return !(e && *e && atoi(e) == 0); }();
         const uint32_t max_items = (uint32_t)std::min<uint64_t>(items_per_batch, std::max<uint32_t>(64u, wf_cap & ~63u));
         std::vector<uint64_t> stat_key = {p.width, p.height, p.samples, p.bounces, (uint64_t)p.brdf,
@@ -1720,14 +1722,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             ee = std::max(ee, ne);
                         }
                 const uint64_t items = std::min<uint64_t>((uint64_t)ca * m, items_per_batch);
-                if (!bounce0_fused) {   // the casts of bounce 0 through the arrays by queue position too (hits, draws, exact list by work item)
-                    hh = std::max(hh, items);
-                    ee = std::max(ee, items);
-                }
+                if (!bounce0_fused) hh = std::max(hh, items);   // the casts of bounce 0 too: hits and draw counts by work item
                 auto pad = [](uint64_t n) { return (std::max<uint64_t>(n, 1024) + 1023) & ~1023ull; };
                 q0 = pad(q0), q1 = pad(q1), hh = pad(hh), ss = pad(ss), ee = pad(ee);
                 const uint64_t bytes = 68u * (q0 + q1) + 20u * hh + (alpha ? 4u * hh : 0u) + (64u + 16u * lights + 4u) * ss + 16u * ee +
-                                       (rng_one_plane ? 16u : 32u) * items;
+                                       (rng_one_plane ? 16u : (wf_overlap && items < items_per_batch) ? 64u : 32u) * items;   // (two copies: the next chunk's are made ahead)
                 if ((bytes <= (uint64_t)(steady_gib * 1073741824.0) || m == 1) && std::max({q0, q1, hh, ss, ee, items}) < 0xffffffffull) {
                     f.plan_cap = (uint32_t)items;
                     f.plan_q[0] = (uint32_t)q0;
@@ -1867,15 +1866,13 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 stats_slots = 0;   // (an earlier frame's line is still on its way)
             }
         }
-        // (only the pipelines with a k_wf_rng launch: a FIFTH stream - the caller's, shadow, wide, exact and this one - makes two
-        // of them share one of the device's four hardware queues (ROCm's default), and every launch of the frame then waits
-        // ~45 us longer for its turn: config 3, 40.3 -> 41.8 ms a frame with the stream merely existing)
-        if (multi_chunk && wf_overlap && !rng_one_plane) {
-            if (!w.side_rng) {
-                HIP_CHECK(hipStreamCreateWithFlags(&w.side_rng, hipStreamNonBlocking));
-                HIP_CHECK(hipEventCreateWithFlags(&w.ev_rng, hipEventDisableTiming));
-                HIP_CHECK(hipEventCreateWithFlags(&w.ev_chunk, hipEventDisableTiming));
-            }
+        // (the next chunk's RNG planes are produced on the SHADOW stream, idle while a chunk's bounce 0 is traced - not on a stream
+        // of their own: a FIFTH stream - the caller's, shadow, wide, exact and that one - makes two of them share one of the
+        // device's four hardware queues (ROCm's default), and every launch of the frame then waits ~45 us longer for its turn:
+        // config 3, 40.3 -> 41.8 ms a frame with the stream merely existing, config 5 465 -> 508 ms)
+        if (multi_chunk && wf_overlap && !rng_one_plane && !w.ev_rng) {
+            HIP_CHECK(hipEventCreateWithFlags(&w.ev_rng, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&w.ev_chunk, hipEventDisableTiming));
         }
         if (wf_overlap && !w.side) {
             HIP_CHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
@@ -1998,7 +1995,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             // the issue slots idle and end in a drain phase)
             // both kinds of grid: the bounce-0 kernel computes the ChaCha block itself (GRID 3)
             const bool fused_rng = rng_one_plane;   // (PT_OG_FUSE_RNG=0: off)
-            const bool rng_ahead = !fused_rng && wf_overlap && total_items > cap && pipe.side_rng != nullptr;
+            const bool rng_ahead = !fused_rng && wf_overlap && total_items > cap && pipe.side != nullptr && pipe.ev_rng != nullptr;
             uint32_t chunk_no = 0;
             for (uint32_t base = 0; base < total_items; base += cap, ++chunk_no) {
                 WfParams W{};
@@ -2054,15 +2051,15 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     Wn.item_base = base + cap;
                     Wn.n_items = std::min(cap, total_items - Wn.item_base);
                     HIP_CHECK(hipEventRecord(pipe.ev_chunk, st_main));
-                    HIP_CHECK(hipStreamWaitEvent(pipe.side_rng, pipe.ev_chunk, 0));
-                    stage_stream = pipe.side_rng;
+                    HIP_CHECK(hipStreamWaitEvent(pipe.side, pipe.ev_chunk, 0));
+                    stage_stream = pipe.side;
                     stage_begin(0);
-                    hipLaunchKernelGGL(k_wf_rng, dim3((Wn.n_items + 255u) / 256u), dim3(256), 0, pipe.side_rng, dev, Wn,
+                    hipLaunchKernelGGL(k_wf_rng, dim3((Wn.n_items + 255u) / 256u), dim3(256), 0, pipe.side, dev, Wn,
                                        d_tiles, (uint4*)pipe.rng[(chunk_no + 1u) & 1u].p);
                     HIP_CHECK(hipGetLastError());
                     stage_end();
                     stage_stream = st_main;
-                    HIP_CHECK(hipEventRecord(pipe.ev_rng, pipe.side_rng));
+                    HIP_CHECK(hipEventRecord(pipe.ev_rng, pipe.side));
                 }
                 for (uint32_t b = 0; b <= p.bounces; ++b) {
                     W.bounce = b;

@@ -1748,13 +1748,15 @@ __global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S,
         FatRay F;
         float r0 = 0.f, r1 = 0.f;
         const bool in_scene = F.init(S, o, d, 0.f, r0, r1);
-        // The alpha walk (mod.rs:188-205) looks at the sorted hit list entry by entry; a walk per entry - from the origin again, with
-        // the entries already seen filtered out - made a translucent cast of config 5 five walks long.  So one walk collects the
-        // KH nearest entries behind (t_prev, ord_prev), in order, and the list is walked from those; only a ray that skips all
-        // KH of them walks again.  (Opaque scenes: KH = 1, the closest hit.)
+        // The alpha walk (mod.rs:188-205) looks at the sorted hit list entry by entry.  The FIRST walk is a closest-hit walk (it
+        // stops at the first leaf with a hit: most first entries are opaque); a ray that skips its first entry walks again and
+        // collects the KH nearest entries behind (t_prev, ord_prev) in one go - such a walk ends only where KH entries lie
+        // before the segment - and the list is walked from those; a ray that skips all KH walks once more.  (A walk per
+        // entry made a translucent cast of config 5 five walks long; KH entries from the first walk on made every cast a walk to
+        // the far end of the scene.  Opaque scenes: KH = 1, the closest hit.)
         constexpr int KH = ALPHA ? 4 : 1;
         RawHit cand[KH], best, kept;
-        bool have_kept = false, hit = false;
+        bool have_kept = false, hit = false, first_walk = true;
         float t_prev = -INFINITY;
         uint32_t ord_prev = 0u;
         best.pid = 0xffffffffu;
@@ -1863,7 +1865,7 @@ __global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S,
                             t1 = ov_t1[sp - WF_EXACT_LDS_STACK];
                         }
                         // (the segment's hits have keys >= t0 * min(1, |d|): beyond the last candidate it holds nothing of interest)
-                        if (!(t0 * key_scale > cand[KH - 1].key + PT_EXIT_ABS)) {
+                        if (!(t0 * key_scale > (first_walk ? cand[0].key : cand[KH - 1].key) + PT_EXIT_ABS)) {
                             more = true;
                             break;
                         }
@@ -1878,9 +1880,12 @@ __global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S,
             }
             hit = false;
             bool walk_again = false;
+            // (the first walk stopped behind its nearest entry: the others it happened to see are not known to be the next ones)
+            const int n_known = (first_walk && nc > 1) ? 1 : nc, last_known = first_walk ? 0 : KH - 1;
+            first_walk = false;
 #pragma unroll
             for (int k = 0; k < KH; ++k) {
-                if (k < nc && !hit) {
+                if (k < n_known && !hit) {
                     best = cand[k];
                     bool stop = true;
                     if (ALPHA) {
@@ -1902,7 +1907,7 @@ __global__ __launch_bounds__(WF_EXACT_THREADS) void k_wf_trace_exact(DevScene S,
                         t_prev = best.key;
                         ord_prev = best.ord;
                         if (COUNT) lc.restarts++;
-                        if (k == KH - 1) walk_again = true;   // (all KH candidates skipped: there may be more behind them)
+                        if (k == last_known) walk_again = true;   // (every known entry skipped: there may be more behind them)
                     }
                 }
             }

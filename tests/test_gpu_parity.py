@@ -874,17 +874,17 @@ def test_config5_full_size(pta, oracle):
 
 @pytest.mark.parametrize("name", ["cube", "alpha_transparency"])
 def test_out_of_memory_falls_back_to_smaller_chunks(pta, scene_cache, name):
-    """The first frame of a configuration takes up to 16 GiB of path queues (~270 B per work item of a chunk).  On a
+    """The first frame of a configuration takes up to 8 GiB of path queues (~270 B per work item of a chunk).  On a
     device that cannot provide them the render must go on with smaller chunks - same bits - instead of failing.
     (The next chunk's RNG planes are produced on a side stream underneath the current chunk, for opaque and
     translucent scenes alike.)"""
     import torch
     scene = scene_cache(name)
-    prof = pta.Profile.make(1920, 1080, 48, 3)            # 99.5 M work items: two chunks of 16 GiB
+    prof = pta.Profile.make(1920, 1080, 48, 3)            # 99.5 M work items: four chunks of 8 GiB
     rgb, acc = pta.GpuScene(scene).render(prof)
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    keep = 10 << 30                                        # leave 10 GiB: forces a halving
+    keep = 5 << 30                                         # leave 5 GiB: forces a halving
     hog = torch.empty(max(0, free - keep), dtype=torch.uint8, device="cuda")
     try:
         g = pta.GpuScene(scene)

@@ -18,6 +18,7 @@ ap.add_argument('--height', type=int, default=1080)
 ap.add_argument('--bounces', type=int, default=5)
 ap.add_argument('--tonemap', default='FILMIC')
 ap.add_argument('--scene-flags', type=int, default=8)
+ap.add_argument('--opt-flags', type=int, default=0)
 a = ap.parse_args()
 if a.what == 'run':
     import torch
@@ -26,7 +27,7 @@ if a.what == 'run':
     pta = e.load_package()
     g = pta.GpuScene(pta.HostScene.generate_ps5(a.tris, 0, a.scene_flags), 0)
     prof = pta.Profile.make(a.width, a.height, a.spp, a.bounces, a.tonemap)
-    opts = pta.Opts.make(flags=0, shard_rank=0, shard_count=a.shards, tile_w=32, tile_h=32)
+    opts = pta.Opts.make(flags=a.opt_flags, shard_rank=0, shard_count=a.shards, tile_w=32, tile_h=32)
     npx = len(pta.local_pixel_map(prof, opts))
     rgb = torch.empty(npx * 3, dtype=torch.uint8, device='cuda')
     acc = torch.empty(npx * 3, dtype=torch.float32, device='cuda')

@@ -1,9 +1,10 @@
 """Randomised differential test of the integrator paths on the GPU: generated scenes (every flag combination the generator
 knows, several sizes and seeds) x random profiles (odd sizes, 1-9 samples, 0-7 bounces, every tone map) x random options
-(shards, tile sizes, sample batches): the default pipeline (origin grids, camera-grid cull, split shade pass, hand-over
-kernel) must equal the KD-tree pipeline and the one-lane-per-pixel megakernel bit for bit, image and f32 accumulation.
+(shards, tile sizes, sample batches, queue budgets): the default pipeline (origin grids, camera-grid cull, split shade pass, hand-over
+kernel) must equal the KD-tree pipeline and the one-lane-per-pixel megakernel bit for bit, image and f32 accumulation;
+so must the second frame of each pipeline, whose queues are sized by the first frame's counts (frame plan).
     python tools/stress_paths.py [seconds] [seed]"""
-import sys, time, pathlib
+import os, sys, time, pathlib
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import numpy as np
 import __graft_entry__ as e
@@ -15,7 +16,7 @@ def run(budget, seed, max_cases=None, verbose=True):
     """Returns (cases, cases with empty blocks, cases also checked against the oracle); raises AssertionError on a mismatch."""
     rng = np.random.default_rng(seed)
     t0 = time.time()
-    cases = culled = with_oracle = 0
+    cases = culled = with_oracle = planned = 0
     last = t0
     while time.time() - t0 < budget and (max_cases is None or cases < max_cases):
         if verbose and time.time() - last > 30:   # (a run on the GPU box must not stay silent)
@@ -34,7 +35,14 @@ def run(budget, seed, max_cases=None, verbose=True):
             rank = int(rng.integers(0, count))
             tile_w, tile_h = [(32, 32), (16, 16), (64, 8), (48, 16), (24, 32), (8, 32)][int(rng.integers(0, 6))]   # (tile_w * tile_h: a multiple of 256)
             kw = dict(shard_rank=rank, shard_count=count, tile_w=tile_w, tile_h=tile_h, sample_batch=int(rng.choice([0, 0, 1, 3])))
-            what = dict(tris=tris, flags=flags, seed=seed_s, w=w, h=h, spp=prof.samples, bounces=prof.bounces, **kw)
+            # queue budgets of the first / the later frames: the defaults, or so little that a frame takes several chunks of 1 Mi items
+            budgets = [(None, None), ("0.001", None), ("0.001", "0.001"), (None, "0.001")][int(rng.integers(0, 4))]
+            for name, val in zip(("PT_QUEUE_GIB", "PT_QUEUE_STEADY_GIB"), budgets):
+                if val is None:
+                    os.environ.pop(name, None)
+                else:
+                    os.environ[name] = val
+            what = dict(tris=tris, flags=flags, seed=seed_s, w=w, h=h, spp=prof.samples, bounces=prof.bounces, budgets=budgets, **kw)
             rgb, acc = g.render(prof, pta.Opts.make(**kw))
             blocks, empty = g.cull_stats()
             culled += empty > 0
@@ -43,6 +51,13 @@ def run(budget, seed, max_cases=None, verbose=True):
                 same = np.array_equal(acc.view(np.uint32), acc2.view(np.uint32)) and np.array_equal(rgb, rgb2)
                 assert same, ("MISMATCH between the default pipeline and path", f, what,
                               np.flatnonzero((acc.view(np.uint32) != acc2.view(np.uint32)).reshape(len(acc), -1).any(1))[:10])
+            # the second frame of a configuration: queues as long as the first frame's counts say
+            for f in (0, pta.PT_FLAG_NO_GRIDS):
+                rgb2, acc2 = g.render(prof, pta.Opts.make(flags=f, **kw))
+                same = np.array_equal(acc.view(np.uint32), acc2.view(np.uint32)) and np.array_equal(rgb, rgb2)
+                assert same and g.info().frame_planned == 1, ("MISMATCH between the first and the planned frame of path", f, what,
+                              np.flatnonzero((acc.view(np.uint32) != acc2.view(np.uint32)).reshape(len(acc), -1).any(1))[:10])
+                planned += 1
             # small whole frames also against the CPU oracle (the restatement of the reference, pinned by its goldens)
             if count == 1 and w * h * prof.samples <= 60000:
                 osc = osc or orc.OracleScene(host_scene.desc, orc.PTO_BVH)
@@ -52,6 +67,8 @@ def run(budget, seed, max_cases=None, verbose=True):
                               np.flatnonzero((acc.view(np.uint32) != o_acc.view(np.uint32)).reshape(len(acc), -1).any(1))[:10])
                 with_oracle += 1
             cases += 1
+    for name in ("PT_QUEUE_GIB", "PT_QUEUE_STEADY_GIB"):
+        os.environ.pop(name, None)
     return cases, culled, with_oracle, time.time() - t0
 
 
