@@ -350,6 +350,15 @@ typedef struct pt_scene_info {
 } pt_scene_info;
 int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out);
 
+/* Experiment (tools/cu_mask_pipelines.py): confine the scene's own streams to the compute units of
+ * `mask` (hipExtStreamCreateWithCUMask; bit i of word i/32 = CU i) and size its grids for their number, so that two
+ * scenes render disjoint tile sets of one frame side by side without taking each other's wave slots.  Before the first
+ * render of the scene.  pt_stream_create_cu_mask makes the caller's stream for pt_render_device the same way.
+ * The reference has no counterpart. */
+int pt_scene_set_cu_mask(pt_scene* scene, const uint32_t* mask, uint32_t n_words);
+int pt_stream_create_cu_mask(int device, const uint32_t* mask, uint32_t n_words, void** out_stream);
+int pt_stream_destroy(void* stream);
+
 /* ------------------------------------------------------------------ */
 /* test hooks (parity tests call the device code piecewise)            */
 /* ------------------------------------------------------------------ */

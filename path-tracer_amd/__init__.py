@@ -177,7 +177,7 @@ HOST_SYMBOLS = ["pth_scene_load_isf", "pth_scene_free", "pth_scene_desc", "pth_s
 GPU_SYMBOLS = ["pt_scene_create", "pt_scene_destroy", "pt_prep_create", "pt_prep_destroy", "pt_scene_create_from_prep",
                "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_gather_tiles", "pt_render_gathered", "pt_local_pixel_count", "pt_local_pixel_map",
                "pt_render", "pt_render_device", "pt_debug_render", "pt_assemble_tiles", "pt_get_timing", "pt_get_counters",
-               "pt_scene_get_info", "pt_get_cull_stats", "pt_scene_escape_copy", "pt_scene_grid_header", "pt_scene_grid_copy", "pt_trace_rays", "pt_trace_rays_wavefront",
+               "pt_scene_get_info", "pt_scene_set_cu_mask", "pt_stream_create_cu_mask", "pt_stream_destroy", "pt_get_cull_stats", "pt_scene_escape_copy", "pt_scene_grid_header", "pt_scene_grid_copy", "pt_trace_rays", "pt_trace_rays_wavefront",
                "pt_trace_rays_all", "pt_intersect_triangles",
                "pt_rng_words", "pt_eval_math", "pt_measure_copy_bandwidth", "pt_measure_gather_rate", "pt_last_error",
                "pt_version"]
@@ -258,6 +258,9 @@ def gpu_lib():
         L.pt_get_timing.argtypes = [vp, C.POINTER(Timing)]
         L.pt_get_counters.argtypes = [vp, C.POINTER(Counters)]
         L.pt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
+        L.pt_scene_set_cu_mask.argtypes = [vp, vp, C.c_uint32]
+        L.pt_stream_create_cu_mask.argtypes = [C.c_int, vp, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.pt_stream_destroy.argtypes = [vp]
         L.pt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp]
         L.pt_trace_rays_wavefront.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, vp]
         L.pt_scene_grid_header.argtypes = [vp, C.c_uint32, vp]

@@ -537,6 +537,8 @@ struct pt_scene {
     mutable uint64_t queue_bytes_last = 0;   // bytes of the path queues of the last frame (pt_scene_get_info)
     mutable uint32_t queue_chunk_last = 0, frame_planned_last = 0;
     mutable int trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
+    // (experiment, pt_scene_set_cu_mask: the scene's own streams confined to these CUs, grids sized for their number)
+    std::vector<uint32_t> cu_mask;
     mutable uint32_t last_mask_blocks = 0;   // blocks of the last frame's camera-grid cull table (0: no cull in that frame)
     mutable uint32_t wf_cap_ok = 0;   // largest queue capacity the device provided so far (0: not tried)
     // tile tables of the sharded renders, one per configuration (image size, rank, count, tile size) and never rewritten:
@@ -1616,7 +1618,18 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         const char* e = getenv("PT_WF_WALK_SHADOW");
         return (uint32_t)(e && *e ? atoi(e) : 12);
     }();
-    if (s.n_cu == 0) HIP_CHECK(hipDeviceGetAttribute(&s.n_cu, hipDeviceAttributeMultiprocessorCount, s.device));
+    if (s.n_cu == 0) {
+        HIP_CHECK(hipDeviceGetAttribute(&s.n_cu, hipDeviceAttributeMultiprocessorCount, s.device));
+        if (!s.cu_mask.empty()) {
+            int bits = 0;
+            for (uint32_t w : s.cu_mask) bits += __builtin_popcount(w);
+            s.n_cu = std::max(1, std::min(s.n_cu, bits));
+        }
+    }
+    auto side_stream = [&s](hipStream_t* st, int priority) {
+        if (!s.cu_mask.empty()) HIP_CHECK(hipExtStreamCreateWithCUMask(st, (uint32_t)s.cu_mask.size(), s.cu_mask.data()));
+        else HIP_CHECK(hipStreamCreateWithPriority(st, hipStreamNonBlocking, priority));
+    };
     uint32_t batch = o.sample_batch ? o.sample_batch : p.samples;
     const bool alpha = s.dev.has_translucent != 0;
     if (mode >= 1) {
@@ -1875,7 +1888,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_chunk, hipEventDisableTiming));
         }
         if (wf_overlap && !w.side) {
-            HIP_CHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+            side_stream(&w.side, 0);
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_shade, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_shadow, hipEventDisableTiming));
         }
@@ -1887,8 +1900,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
             const char* pe = getenv("PT_WF_SIDE_PRIORITY");
             const int prio = (pe && *pe && atoi(pe) == 0) ? prio_lo : prio_hi;
-            HIP_CHECK(hipStreamCreateWithPriority(&w.side_wide, hipStreamNonBlocking, prio));
-            HIP_CHECK(hipStreamCreateWithPriority(&w.side_exact, hipStreamNonBlocking, prio));
+            side_stream(&w.side_wide, prio);
+            side_stream(&w.side_exact, prio);
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_trace, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_wide, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&w.ev_exact, hipEventDisableTiming));
@@ -2835,6 +2848,30 @@ int pt_get_cull_stats(const pt_scene* scene, uint32_t* n_blocks, uint32_t* n_emp
         }
     });
 }
+int pt_scene_set_cu_mask(pt_scene* scene, const uint32_t* mask, uint32_t n_words) {
+    return guarded([&] {
+        if (!scene || (n_words && !mask)) fail(PT_ERR_INVALID, "pt_scene_set_cu_mask: null argument");
+        if (scene->pipe.side || scene->n_cu) fail(PT_ERR_INVALID, "pt_scene_set_cu_mask: the scene has rendered already");
+        scene->cu_mask.assign(mask, mask + n_words);
+    });
+}
+
+int pt_stream_create_cu_mask(int device, const uint32_t* mask, uint32_t n_words, void** out) {
+    return guarded([&] {
+        if (!mask || !n_words || !out) fail(PT_ERR_INVALID, "pt_stream_create_cu_mask: null argument");
+        HIP_CHECK(hipSetDevice(device));
+        hipStream_t st = nullptr;
+        HIP_CHECK(hipExtStreamCreateWithCUMask(&st, n_words, mask));
+        *out = (void*)st;
+    });
+}
+
+int pt_stream_destroy(void* stream) {
+    return guarded([&] {
+        if (stream) HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    });
+}
+
 int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out) {
     if (!scene || !out) return PT_ERR_INVALID;
     *out = scene->info;
