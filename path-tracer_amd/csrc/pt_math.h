@@ -55,6 +55,18 @@ PT_HD uint8_t as_u8(float v) {
 }
 // `x as i64` then rem_euclid(n) for texture wrap (internal/material.rs:115-130).
 PT_HD uint32_t wrap_texel(float c, uint32_t n) {
+#ifndef PT_WRAP_SLOW   // (A/B builds: the 64-bit form for every coordinate)
+    // Every sane texture coordinate: |c| < 2^31, the conversion is exact in 32 bits and the remainder needs no 64-bit division
+    // (the signed 64-bit `%` below is ~1100 of the bounce-0 kernel's ~6500 vector instructions, twice per texel fetch); a
+    // power-of-two size needs no division at all (two's complement: i & (n - 1) IS the Euclidean remainder).
+    if (fabsf(c) < 2147483648.0f && n != 0u) {   // (NaN: the general form)
+        const int32_t i32 = (int32_t)c;
+        if ((n & (n - 1u)) == 0u) return (uint32_t)i32 & (n - 1u);
+        const uint32_t a = i32 < 0 ? 0u - (uint32_t)i32 : (uint32_t)i32;
+        const uint32_t q = a % n;
+        return (i32 < 0 && q != 0u) ? n - q : q;
+    }
+#endif
     long long i;
     if (!(c == c)) i = 0;
     else if (c >= 9223372036854775807.0f) i = 0x7fffffffffffffffLL;
