@@ -521,11 +521,13 @@ struct pt_scene {
         uint32_t* host = nullptr;                         // pinned: n_slots x levels x 4 words (queue, shadow, exact, offgrid | overflow)
         hipEvent_t done = nullptr;
         bool pending = false, valid = false, planned = false;
+        bool stats_planned = false;   // the counts on their way were taken by a frame that ran the plan
         std::vector<uint32_t> first_item_of_slot;         // (which chunk a slot was)
         // the plan made from them: work items per chunk, records per queue / hit / shadow / exact array, the bounces whose
         // shadow casts go inline; fresh until its buffers have been allocated once (buffers much larger are given back then)
         uint32_t plan_cap = 0, plan_q[2] = {0, 0}, plan_h = 0, plan_s = 0, plan_e = 0;
         std::vector<uint8_t> plan_inline;
+        std::vector<uint32_t> plan_last;   // per chunk of the plan: the last bounce that has a ray (later ones are not launched)
         bool plan_fresh = false, plan_failed = false;   // (failed: the device could not provide the plan's buffers)
         ~FrameStats() {
             if (host) (void)hipHostFree(host);
@@ -1646,7 +1648,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     uint32_t cap_q[2] = {0, 0}, cap_h = 0, cap_s = 0, cap_e = 0;
     std::vector<uint8_t> inline_at(p.bounces + 2, 0);   // bounces >= 1 whose shadow casts run inside the shade kernel
     pt_scene::FrameStats* fs = nullptr;
-    bool multi_chunk = false, rng_one_plane = false;
+    bool multi_chunk = false, rng_one_plane = false, skip_dead = false;
     uint32_t stats_slots = 0;
     if (mode == 2) {
         uint64_t items_per_batch = (uint64_t)blocks64 * 64u * batch;
@@ -1685,6 +1687,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         // Later frames 16 GiB: config 3 in one pass (13.8 GiB), the closed room in 5 (32 GiB: 3 passes, 1.7 % faster).
         const double first_gib = [] { const char* e = getenv("PT_QUEUE_GIB"); return e && *e ? atof(e) : 8.0; }();
         const double steady_gib = [first_gib] { const char* e = getenv("PT_QUEUE_STEADY_GIB"); return e && *e ? atof(e) : std::max(first_gib, 16.0); }();
+        static const bool skip_dead_env = [] { const char* e = getenv("PT_PLAN_SKIP"); return !(e && *e && atoi(e) == 0); }();
+        skip_dead = skip_dead_env;
         static const bool inline_auto = [] { const char* e = getenv("PT_OG_INLINE_AUTO"); return !(e && *e && atoi(e) == 0); }();
         const uint32_t max_items = (uint32_t)std::min<uint64_t>(items_per_batch, std::max<uint32_t>(64u, wf_cap & ~63u));
         std::vector<uint64_t> stat_key = {p.width, p.height, p.samples, p.bounces, (uint64_t)p.brdf,
@@ -1714,8 +1718,10 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             for (uint32_t m = m_max; m >= 1; --m) {
                 uint64_t q1 = 0, q0 = 0, hh = 0, ss = 0, ee = 0;
                 std::vector<uint64_t> tot_q(lv, 0), tot_s(lv, 0);
+                std::vector<uint32_t> last;
                 for (auto& bt : batches)
-                    for (size_t g0 = 0; g0 < bt.size(); g0 += m)
+                    for (size_t g0 = 0; g0 < bt.size(); g0 += m) {
+                        last.push_back(0u);
                         for (uint32_t b = 0; b < lv; ++b) {
                             uint64_t nq = 0, ns = 0, ne = 0;
                             for (size_t k = g0; k < std::min(bt.size(), g0 + m); ++k) {
@@ -1726,6 +1732,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             }
                             tot_q[b] += nq;
                             tot_s[b] += ns;
+                            if (b >= 1 && nq != 0) last.back() = b;
                             if (b >= 1) {   // (queue b lives in queue[b & 1]; the hits of its casts by queue position)
                                 uint64_t& q = (b & 1u) ? q1 : q0;
                                 q = std::max(q, nq);
@@ -1734,6 +1741,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                             ss = std::max(ss, ns);
                             ee = std::max(ee, ne);
                         }
+                    }
                 const uint64_t items = std::min<uint64_t>((uint64_t)ca * m, items_per_batch);
                 if (!bounce0_fused) hh = std::max(hh, items);   // the casts of bounce 0 too: hits and draw counts by work item
                 auto pad = [](uint64_t n) { return (std::max<uint64_t>(n, 1024) + 1023) & ~1023ull; };
@@ -1752,6 +1760,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     f.plan_inline.assign(p.bounces + 2, 0);
                     if (inline_auto && use_light_grids)
                         for (uint32_t b = 1; b < lv && b < f.plan_inline.size(); ++b) f.plan_inline[b] = tot_q[b] > 0 && tot_s[b] * 10 >= tot_q[b] * 6;
+                    f.plan_last = last;
                     f.plan_fresh = true;
                     if (const char* e = getenv("PT_PLAN_DEBUG"); e && *e && atoi(e)) {
                         fprintf(stderr, "[ptgpu] frame plan: %u chunks of %u -> 1 of %llu items; queues %llu / %llu, hits %llu, shadow %llu, exact %llu records; %.3f GiB\n",
@@ -1782,7 +1791,12 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 if (q == hipSuccess) {
                     fs->pending = false;
                     bool overflow = false;
-                    for (uint32_t k = 0; k < fs->n_slots; ++k) overflow = overflow || fs->host[(size_t)k * fs->levels * 4 + 3] != 0u;
+                    for (uint32_t k = 0; k < fs->n_slots; ++k) {
+                        overflow = overflow || fs->host[(size_t)k * fs->levels * 4 + 3] != 0u;
+                        if (fs->planned && fs->stats_planned && k < fs->plan_last.size())   // (a ray at a bounce the plan did not launch)
+                            for (uint32_t b = fs->plan_last[k] + 1u; b < fs->levels; ++b)
+                                overflow = overflow || fs->host[((size_t)k * fs->levels + b) * 4] != 0u;
+                    }
                     if (overflow) {
                         // cannot happen (the counts of a configuration do not change): a queue sized from them ran full
                         fs->valid = fs->planned = false;
@@ -1873,6 +1887,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 }
                 if (!fs->done) HIP_CHECK(hipEventCreateWithFlags(&fs->done, hipEventDisableTiming));
                 fs->cap_items = cap;
+                fs->stats_planned = exact;
                 fs->first_item_of_slot.assign(stats_slots, 0u);
                 s.stats_dev.ensure((size_t)stats_slots * levels * 16u);
             } else {
@@ -1983,7 +1998,8 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         block_empty = (const uint32_t*)s.pipe.block_mask.p;
     }
     s.last_mask_blocks = block_empty ? blocks64 : 0u;
-    uint32_t stats_line = 0;
+    uint32_t stats_line = 0, chunk_slot = 0;
+    const std::vector<uint32_t>* plan_last = (fs && s.frame_planned_last && skip_dead) ? &fs->plan_last : nullptr;
     for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
         P.sample_begin = s0;
         P.sample_end = std::min(p.samples, s0 + batch);
@@ -2074,7 +2090,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     stage_stream = st_main;
                     HIP_CHECK(hipEventRecord(pipe.ev_rng, pipe.side));
                 }
-                for (uint32_t b = 0; b <= p.bounces; ++b) {
+                // (the plan knows where this chunk's last ray ends: the launches of the bounces behind it - ~85 us each for nothing -
+                // are not made; PT_PLAN_SKIP=0: all of them)
+                const uint32_t b_end = (plan_last && chunk_slot < plan_last->size()) ? std::min(p.bounces, (*plan_last)[chunk_slot]) : p.bounces;
+                ++chunk_slot;
+                for (uint32_t b = 0; b <= b_end; ++b) {
                     W.bounce = b;
                     W.qcap_in = cap_q[b & 1u];          // (queue b lives in pipe.queue[b & 1])
                     W.qcap_out = cap_q[(b + 1u) & 1u];
