@@ -374,7 +374,10 @@ def main():
         traffic = valu_rate = traffic_src = lanes = None
         got = pmc_of(name)
         if got:
-            traffic = got[1].get("hbm_bytes_per_launch")
+            # per launch like `achieved`: the record's bytes per FRAME over this run's launches per frame (the profiled run's
+            # first frame also launches the bounces behind the last ray, which the planned frames timed here do not)
+            traffic = (got[1]["hbm_bytes_per_frame"] / max(1, dom["launches_per_frame"]) if got[1].get("hbm_bytes_per_frame")
+                       else got[1].get("hbm_bytes_per_launch"))
             valu_rate = got[1].get("valu_insts_per_cu_cycle")
             lanes = got[1].get("active_lanes_per_valu_inst")
             traffic_src = f"profiles/latest_traffic.json <- {rec.get('source')} ({got[0]}), device code {rec.get('kernel_source_sha16')}"
