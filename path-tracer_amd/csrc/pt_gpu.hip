@@ -1686,6 +1686,7 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         // render_s with 2 / 4 / 8 / 16 / 64 GiB: 0.121 / 0.095 / 0.080 / 0.136-0.29 / 1.69 s - the frame itself is 0.04-0.05 s).
         // Later frames 16 GiB: config 3 in one pass (13.8 GiB), the closed room in 5 (32 GiB: 3 passes, 1.7 % faster).
         const double first_gib = [] { const char* e = getenv("PT_QUEUE_GIB"); return e && *e ? atof(e) : 8.0; }();
+        const double one_pass_gib = [] { const char* e = getenv("PT_QUEUE_ONE_PASS_GIB"); return e && *e ? atof(e) : 32.0; }();
         const double steady_gib = [first_gib] { const char* e = getenv("PT_QUEUE_STEADY_GIB"); return e && *e ? atof(e) : std::max(first_gib, 16.0); }();
         static const bool skip_dead_env = [] { const char* e = getenv("PT_PLAN_SKIP"); return !(e && *e && atoi(e) == 0); }();
         skip_dead = skip_dead_env;
@@ -1748,7 +1749,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                 q0 = pad(q0), q1 = pad(q1), hh = pad(hh), ss = pad(ss), ee = pad(ee);
                 const uint64_t bytes = 68u * (q0 + q1) + 20u * hh + (alpha ? 4u * hh : 0u) + (64u + 16u * lights + 4u) * ss + 16u * ee +
                                        (rng_one_plane ? 16u : (wf_overlap && items < items_per_batch) ? 64u : 32u) * items;   // (two copies: the next chunk's are made ahead)
-                if ((bytes <= (uint64_t)(steady_gib * 1073741824.0) || m == 1) && std::max({q0, q1, hh, ss, ee, items}) < 0xffffffffull) {
+                // (a batch that fits `one_pass_gib` as ONE chunk takes it: every extra pass repeats the persistent launches and their
+                // drains - the KD-tree pipeline of config 3, 29.7 GiB in one pass: 62.4 ms, in three passes of 16 GiB 75.3 ms)
+                const bool fits = bytes <= (uint64_t)(steady_gib * 1073741824.0) ||
+                                  (items >= items_per_batch && bytes <= (uint64_t)(one_pass_gib * 1073741824.0));
+                if ((fits || m == 1) && std::max({q0, q1, hh, ss, ee, items}) < 0xffffffffull) {
                     f.plan_cap = (uint32_t)items;
                     f.plan_q[0] = (uint32_t)q0;
                     f.plan_q[1] = (uint32_t)q1;
@@ -2098,7 +2103,9 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                     W.bounce = b;
                     W.qcap_in = cap_q[b & 1u];          // (queue b lives in pipe.queue[b & 1])
                     W.qcap_out = cap_q[(b + 1u) & 1u];
-                    W.walk_steps = wf_walk ? wf_walk : (b == 0 ? 20u : 12u);
+                    // (node steps per walking phase: 12 until the escape masks took the short casts out of the queues; re-swept on the rays that
+                    // are left - 12 / 14 / 16 / 18: config 3 40.3-40.8 / 40.3-40.4 / 39.7-39.8 / 39.8-40.0 ms, closed room 173.9 -> 171.4)
+                    W.walk_steps = wf_walk ? wf_walk : (b == 0 ? 20u : 16u);
                     float4* q_in = (float4*)pipe.queue[b & 1].p;
                     float4* q_out = (float4*)pipe.queue[(b + 1) & 1].p;
                     const bool prim = fused_primary && b == 0;

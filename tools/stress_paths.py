@@ -37,7 +37,7 @@ def run(budget, seed, max_cases=None, verbose=True):
             kw = dict(shard_rank=rank, shard_count=count, tile_w=tile_w, tile_h=tile_h, sample_batch=int(rng.choice([0, 0, 1, 3])))
             # queue budgets of the first / the later frames: the defaults, or so little that a frame takes several chunks of 1 Mi items
             budgets = [(None, None), ("0.001", None), ("0.001", "0.001"), (None, "0.001")][int(rng.integers(0, 4))]
-            for name, val in zip(("PT_QUEUE_GIB", "PT_QUEUE_STEADY_GIB"), budgets):
+            for name, val in zip(("PT_QUEUE_GIB", "PT_QUEUE_STEADY_GIB", "PT_QUEUE_ONE_PASS_GIB"), budgets + (budgets[1],)):
                 if val is None:
                     os.environ.pop(name, None)
                 else:
@@ -67,7 +67,7 @@ def run(budget, seed, max_cases=None, verbose=True):
                               np.flatnonzero((acc.view(np.uint32) != o_acc.view(np.uint32)).reshape(len(acc), -1).any(1))[:10])
                 with_oracle += 1
             cases += 1
-    for name in ("PT_QUEUE_GIB", "PT_QUEUE_STEADY_GIB"):
+    for name in ("PT_QUEUE_GIB", "PT_QUEUE_STEADY_GIB", "PT_QUEUE_ONE_PASS_GIB"):
         os.environ.pop(name, None)
     return cases, culled, with_oracle, time.time() - t0
 
