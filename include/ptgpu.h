@@ -354,6 +354,9 @@ int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out);
  * `mask` (hipExtStreamCreateWithCUMask; bit i of word i/32 = CU i) and size its grids for their number, so that two
  * scenes render disjoint tile sets of one frame side by side without taking each other's wave slots.  Before the first
  * render of the scene.  pt_stream_create_cu_mask makes the caller's stream for pt_render_device the same way.
+ * Experiment only (measured, rejected: DESIGN.md section 8), not covered by the test suite: on ROCm 7.2 a process that has
+ * created and destroyed CU-masked streams crashed inside the runtime when a later scene's kernels were first launched with
+ * little device memory left (the out-of-memory fallback test run after a masked render; same frames bit for bit otherwise).
  * The reference has no counterpart. */
 int pt_scene_set_cu_mask(pt_scene* scene, const uint32_t* mask, uint32_t n_words);
 int pt_stream_create_cu_mask(int device, const uint32_t* mask, uint32_t n_words, void** out_stream);

@@ -1829,10 +1829,15 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         // allocation; a device that cannot provide the buffers (shared GPU) gets half-size chunks with every queue as long as
         // the chunk, and so on, down to 1 Mi items
         const bool give_back = exact && fs->plan_fresh;   // (a new plan gives memory back, once)
-        auto fit = [give_back](DeviceBuffer& b, size_t n) {
+        bool grew = false;
+        auto fit = [give_back, &grew](DeviceBuffer& b, size_t n) {
             if (give_back && b.bytes > n + n / 4 + (64u << 20)) b.release();
+            grew = grew || b.bytes < n;
             return b.try_ensure(n);
         };
+        // (what the queues must leave free: the runtime allocates the kernels' scratch - up to 592 B per lane of every wave slot
+        // of the device, per hardware queue: ~1.2 GB - when they are first launched, and dies if it cannot)
+        const double reserve_gib = [] { const char* e = getenv("PT_QUEUE_RESERVE_GIB"); return e && *e ? atof(e) : 2.0; }();
         while (true) {
             multi_chunk = (uint64_t)cap < items_per_batch;
             const bool two_rng = !rng_one_plane && multi_chunk && wf_overlap;
@@ -1849,6 +1854,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
                       (!wf_defer ||
                        w.deferred.try_ensure((wf_allwide && !alpha ? (size_t)std::max(cap_q[0], cap_q[1]) : (size_t)s.trace_blocks * WF_THREADS) * 4u *
                                              (alpha ? WF_LIST_WORDS_ALPHA : WF_LIST_WORDS_OPAQUE)));
+            if (ok && grew && cap > (1u << 20)) {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b < reserve_gib * 1073741824.0) ok = false;
+                grew = false;
+            }
             if (ok) {
                 if (exact) fs->plan_fresh = false;
                 break;

@@ -83,37 +83,3 @@ def test_frames_in_flight_do_not_wait_for_the_counts(pta, scene_cache):
     for r, a in outs:
         assert np.array_equal(r.cpu().numpy().reshape(-1, 3), rgb)
         assert np.array_equal(bits(a.cpu().numpy().reshape(-1, 3)), bits(acc))
-
-
-def test_cu_masked_scene_renders_the_same_bits(pta, scene_cache):
-    """pt_scene_set_cu_mask / pt_stream_create_cu_mask (the sub-pipeline experiment of DESIGN section 8): a scene confined to
-    half of the compute units, grids sized for their number, on a masked stream - same frame."""
-    import ctypes as C
-    import torch
-    scene = scene_cache("head")
-    prof = pta.Profile.make(320, 200, 8, 4)
-    rgb, acc = pta.GpuScene(scene).render(prof)
-    lib = pta.gpu_lib()
-    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
-    words = (n_cu + 31) // 32
-    mask = (C.c_uint32 * words)()
-    for cu in range(0, n_cu, 2):
-        mask[cu // 32] |= 1 << (cu % 32)
-    g = pta.GpuScene(scene)
-    pta.check_gpu(lib.pt_scene_set_cu_mask(g.handle, mask, words))
-    h = C.c_void_p()
-    pta.check_gpu(lib.pt_stream_create_cu_mask(0, mask, words, C.byref(h)))
-    try:
-        n = prof.width * prof.height
-        d_rgb = torch.empty(n * 3, dtype=torch.uint8, device="cuda")
-        d_acc = torch.empty(n * 3, dtype=torch.float32, device="cuda")
-        for _ in range(3):
-            g.render_device(prof, pta.Opts.make(), d_rgb.data_ptr(), d_acc.data_ptr(), h.value)
-            torch.cuda.synchronize()
-        assert np.array_equal(d_rgb.cpu().numpy().reshape(-1, 3), rgb)
-        assert np.array_equal(bits(d_acc.cpu().numpy().reshape(-1, 3)), bits(acc))
-        with pytest.raises(pta.PtError):      # (only before the first render)
-            pta.check_gpu(lib.pt_scene_set_cu_mask(g.handle, mask, words))
-    finally:
-        g.close()
-        pta.check_gpu(lib.pt_stream_destroy(h.value))
