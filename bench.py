@@ -227,8 +227,10 @@ def main():
 
     # (the FIRST frame of a configuration runs in fixed-budget chunks and counts what every bounce produces; the frame after it
     # allocates the queues those counts ask for - pt_gpu.hip "frame plan".  Steady state is what the metric is quoted on: a
-    # warm-up of at least two frames, each complete before the next is planned; --warmup 0 times the cold frames)
-    warm_frames = 0 if args.warmup == 0 else max(2, args.warmup)
+    # warm-up of at least four frames, each complete before the next is planned; --warmup 0 times the cold frames
+    # (... and a scene builds its escape masks when it is about to render its third frame - a one-shot render is better off
+    # without them -, after which the plan is made again: frames 1-2 without masks, 3 with masks counting, 4 planned)
+    warm_frames = 0 if args.warmup == 0 else max(4, args.warmup)
     for _ in range(warm_frames):
         step()
         torch.cuda.synchronize()
@@ -244,6 +246,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     q_info = gscene.info().as_dict()
+    info.update({k: q_info[k] for k in ("escape_build_seconds", "escape_prims", "escape_clear_fraction", "device_bytes")})   # (built at frame 3)
     render_ms = sum(a.elapsed_time(b) for a, b, _ in ev_render) / args.steps     # this rank's frame (device time)
     gather_ms = sum(b.elapsed_time(c) for _, b, c in ev_render) / args.steps if world > 1 else 0.0
     per_rank = None
@@ -475,7 +478,7 @@ def main():
         gscene.close()
         scene0 = pta.HostScene.generate_ps5(args.tris, 0, 0)
         g0 = pta.GpuScene(scene0, device=local_rank)
-        for _ in range(max(2, args.warmup)):
+        for _ in range(max(4, args.warmup)):
             g0.render_device(prof, opts_plain, rgb_local.data_ptr(), acc_local.data_ptr(), stream)
             torch.cuda.synchronize()
         t1 = time.perf_counter()

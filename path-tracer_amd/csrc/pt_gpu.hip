@@ -538,6 +538,10 @@ struct pt_scene {
     mutable DeviceBuffer stats_dev;
     mutable uint64_t queue_bytes_last = 0;   // bytes of the path queues of the last frame (pt_scene_get_info)
     mutable uint32_t queue_chunk_last = 0, frame_planned_last = 0;
+    // escape masks: wanted (PT_ESCAPE), built when the scene has rendered `escape_after` frames of the default pipeline
+    bool escape_wanted = false, escape_tried = false;
+    uint32_t escape_after = 2;
+    mutable uint32_t frames_rendered = 0;
     mutable int trace_blocks = 0, shadow_blocks = 0, n_cu = 0;
     // (experiment, pt_scene_set_cu_mask: the scene's own streams confined to these CUs, grids sized for their number)
     std::vector<uint32_t> cu_mask;
@@ -1262,6 +1266,65 @@ void grids_on_device(const pt_prep& P, pt_scene& s) {
 }
 
 // Copy a prepared scene to `device`.
+// The escape masks of a scene (pt_escape.h), built on its device from the uploaded arrays: one wavefront per primitive.  Blocks
+// until they are there (every frame in flight has completed by then).  A device without the memory for them goes without.
+void escape_masks_build(pt_scene& s) {
+    s.escape_tried = true;
+    DevScene& D = s.dev;
+    const uint64_t n_prims = D.n_prims;
+    auto t_esc = std::chrono::steady_clock::now();
+    const size_t mark = s.allocations.size();
+    const uint64_t bytes_mark = s.info.device_bytes;
+    try {
+        HIP_CHECK(hipSetDevice(s.device));
+        void* buf = nullptr;
+        HIP_CHECK(hipMalloc(&buf, n_prims * 80));
+        s.allocations.push_back(buf);
+        s.info.device_bytes += n_prims * 80;
+        uint32_t* d_stats = nullptr;
+        HIP_CHECK(hipMalloc((void**)&d_stats, 16));
+        HIP_CHECK(hipMemset(d_stats, 0, 16));
+        // the largest distance a ray of this scene covers before it hits anything: the box diagonal, or camera to far corner
+        double diag2 = 0, cam2 = 0, amax = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double w = (double)D.bounds_max[a] - D.bounds_min[a], c = D.cam_c3[a];
+            const double far = std::max(std::fabs(c - D.bounds_min[a]), std::fabs(c - D.bounds_max[a]));
+            diag2 += w * w;
+            cam2 += far * far;
+            amax = std::max({amax, std::fabs((double)D.bounds_min[a]), std::fabs((double)D.bounds_max[a]), std::fabs(c)});
+        }
+        const double reach = std::sqrt(std::max(diag2, cam2));
+        EscBuildParams E{};
+        E.delta_in = (float)((double)PT_SLACK_K * reach + 4.0 * 5.9604645e-8 * amax);
+        E.slop_far = E.delta_in;
+        E.alpha_stop = [] { const char* e = getenv("PT_ESCAPE_ALPHA"); return e && *e ? (float)atof(e) : 0.04f; }();
+        E.r_near_scale = 2.0f;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_prims + 3) / 4, 256u * 64u);
+        hipLaunchKernelGGL(k_escape_build, dim3(blocks), dim3(256), 0, 0, D, E, (float4*)buf, (uint32_t)n_prims, d_stats);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        uint32_t st[4] = {0, 0, 0, 0};
+        HIP_CHECK(hipMemcpy(st, d_stats, 16, hipMemcpyDeviceToHost));
+        (void)hipFree(d_stats);
+        D.escape = (const float4*)buf;
+        s.info.escape_prims = st[0];
+        s.info.escape_clear_fraction = st[0] ? (float)((double)st[1] / (384.0 * st[0])) : 0.f;
+    } catch (const GpuError&) {   // (no memory for them: the casts are simply made)
+        while (s.allocations.size() > mark) {
+            (void)hipFree(s.allocations.back());
+            s.allocations.pop_back();
+        }
+        s.info.device_bytes = bytes_mark;
+        D.escape = nullptr;
+    }
+    s.info.escape_build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_esc).count();
+    // the counts of the frames rendered so far are upper bounds now (the masks end paths): the next frame counts again
+    for (auto& kv : s.frame_stats) {
+        pt_scene::FrameStats& f = *kv.second;
+        f.pending = f.valid = f.planned = f.plan_failed = false;
+    }
+}
+
 void scene_upload(const pt_prep& P, int device, pt_scene& s) {
     select_device(device);
     int cur = 0;
@@ -1284,7 +1347,9 @@ void scene_upload(const pt_prep& P, int device, pt_scene& s) {
     D.texels = s.upload(P.texels.data(), P.texels.size());
     D.srgb_lut = s.upload(P.lut, 256);
     D.lights = s.upload(P.lights.data(), P.lights.size());
-    // ---- escape masks (pt_escape.h): built here, on the device, from the arrays just uploaded (one wavefront per primitive)
+    // ---- escape masks (pt_escape.h): built on the device from these arrays - not here: when the scene is about to render its
+    // THIRD frame (escape_masks_build below).  They take 0.14 s for the 0.5 M primitives of config 3 and 1.3 s for the 4 M of
+    // config 5 and return 3 ms and ~0.1 s per frame: a one-shot render (the CLI) is better off without them.
     D.escape = nullptr;
     s.info.escape_build_seconds = 0.f;
     s.info.escape_prims = 0;
@@ -1293,53 +1358,9 @@ void scene_upload(const pt_prep& P, int device, pt_scene& s) {
         const char* esc_env = getenv("PT_ESCAPE");   // (read per scene: the tests switch it)
         const bool esc_on = !(esc_env && *esc_env && atoi(esc_env) == 0);
         const uint64_t n_prims = P.pos.size() / 3;
-        if (esc_on && n_prims > 0 && n_prims < (1ull << 28)) {
-            auto t_esc = std::chrono::steady_clock::now();
-            const size_t mark = s.allocations.size();
-            const uint64_t bytes_mark = s.info.device_bytes;
-            try {
-                void* buf = nullptr;
-                HIP_CHECK(hipMalloc(&buf, n_prims * 80));
-                s.allocations.push_back(buf);
-                s.info.device_bytes += n_prims * 80;
-                uint32_t* d_stats = nullptr;
-                HIP_CHECK(hipMalloc((void**)&d_stats, 16));
-                HIP_CHECK(hipMemset(d_stats, 0, 16));
-                // the largest distance a ray of this scene covers before it hits anything: the box diagonal, or camera to far corner
-                double diag2 = 0, cam2 = 0, amax = 0;
-                for (int a = 0; a < 3; ++a) {
-                    const double w = (double)D.bounds_max[a] - D.bounds_min[a], c = D.cam_c3[a];
-                    const double far = std::max(std::fabs(c - D.bounds_min[a]), std::fabs(c - D.bounds_max[a]));
-                    diag2 += w * w;
-                    cam2 += far * far;
-                    amax = std::max({amax, std::fabs((double)D.bounds_min[a]), std::fabs((double)D.bounds_max[a]), std::fabs(c)});
-                }
-                const double reach = std::sqrt(std::max(diag2, cam2));
-                EscBuildParams E{};
-                E.delta_in = (float)((double)PT_SLACK_K * reach + 4.0 * 5.9604645e-8 * amax);
-                E.slop_far = E.delta_in;
-                E.alpha_stop = [] { const char* e = getenv("PT_ESCAPE_ALPHA"); return e && *e ? (float)atof(e) : 0.04f; }();
-                E.r_near_scale = 2.0f;
-                const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_prims + 3) / 4, 256u * 64u);
-                hipLaunchKernelGGL(k_escape_build, dim3(blocks), dim3(256), 0, 0, D, E, (float4*)buf, (uint32_t)n_prims, d_stats);
-                HIP_CHECK(hipGetLastError());
-                HIP_CHECK(hipDeviceSynchronize());
-                uint32_t st[4] = {0, 0, 0, 0};
-                HIP_CHECK(hipMemcpy(st, d_stats, 16, hipMemcpyDeviceToHost));
-                (void)hipFree(d_stats);
-                D.escape = (const float4*)buf;
-                s.info.escape_prims = st[0];
-                s.info.escape_clear_fraction = st[0] ? (float)((double)st[1] / (384.0 * st[0])) : 0.f;
-            } catch (const GpuError&) {   // (no memory for them: the casts are simply made)
-                while (s.allocations.size() > mark) {
-                    (void)hipFree(s.allocations.back());
-                    s.allocations.pop_back();
-                }
-                s.info.device_bytes = bytes_mark;
-                D.escape = nullptr;
-            }
-            s.info.escape_build_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_esc).count();
-        }
+        s.escape_wanted = esc_on && n_prims > 0 && n_prims < (1ull << 28);
+        const char* after = getenv("PT_ESCAPE_AFTER");   // frames a scene renders without them (0: built for the first frame)
+        s.escape_after = after && *after ? (uint32_t)atoi(after) : 2u;
     }
     auto upload_grid = [&](const pth_origin_grid& g, DevGrid& out) {
         memset(&out, 0, sizeof out);
@@ -1444,6 +1465,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
     HIP_CHECK(hipSetDevice(s.device));
     TileMap tm = make_tile_map(p, o, o.shard_rank);
     if (tm.n_local == 0) return;
+    // escape masks: from the scene's (escape_after + 1)th frame of the default pipeline on (scene_upload has the reason)
+    if (s.escape_wanted && !s.escape_tried && !(o.flags & (PT_FLAG_NO_GRIDS | PT_FLAG_MEGAKERNEL))) {
+        if (s.frames_rendered >= s.escape_after) escape_masks_build(const_cast<pt_scene&>(s));
+        ++s.frames_rendered;
+    }
     // the scene as the kernels of THIS frame see it: the KD-tree pipeline (PT_FLAG_NO_GRIDS) - the cross-check of the parity
     // tests - knows no escape masks either
     DevScene dev = s.dev;
@@ -3023,6 +3049,7 @@ int pt_trace_rays_wavefront(const pt_scene* scene, const float* rays, const uint
 int pt_scene_escape_copy(const pt_scene* scene, void* out, uint64_t bytes) {
     return guarded([&] {
         if (!scene || !out) fail(PT_ERR_INVALID, "pt_scene_escape_copy: null argument");
+        if (!scene->dev.escape && scene->escape_wanted && !scene->escape_tried) escape_masks_build(const_cast<pt_scene&>(*scene));
         if (!scene->dev.escape) fail(PT_ERR_INVALID, "pt_scene_escape_copy: the scene has no escape masks");
         if (bytes != (uint64_t)scene->dev.n_prims * 80u) fail(PT_ERR_INVALID, "pt_scene_escape_copy: %llu bytes expected", (unsigned long long)scene->dev.n_prims * 80ull);
         HIP_CHECK(hipSetDevice(scene->device));

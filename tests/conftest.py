@@ -7,6 +7,11 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import __graft_entry__ as entry  # noqa: E402
 
+# A scene builds its escape masks when it is about to render its third frame (a one-shot render is better off without them,
+# csrc/pt_gpu.hip scene_upload); the tests render one or two frames per scene and mean to test the masked pipeline: from frame one.
+import os  # noqa: E402
+os.environ.setdefault("PT_ESCAPE_AFTER", "0")
+
 GOLDEN = ROOT / "tests" / "golden"
 SCENES = GOLDEN / "scenes"
 

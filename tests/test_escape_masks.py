@@ -71,8 +71,8 @@ def test_rays_through_clear_cells_hit_nothing(pta, oracle, scene_cache, what):
     else:
         scene = scene_cache(what)
     g = pta.GpuScene(scene)
+    masks = g.escape_masks()    # (builds them if the scene has not rendered yet)
     info = g.info()
-    masks = g.escape_masks()
     assert info.escape_prims == int((np.abs(masks[0]).sum(axis=1) > 0).sum())
     rays, prims = rays_through_clear_cells(scene, masks, 60000, seed=9)
     if rays is None:

@@ -83,3 +83,20 @@ def test_frames_in_flight_do_not_wait_for_the_counts(pta, scene_cache):
     for r, a in outs:
         assert np.array_equal(r.cpu().numpy().reshape(-1, 3), rgb)
         assert np.array_equal(bits(a.cpu().numpy().reshape(-1, 3)), bits(acc))
+
+
+def test_escape_masks_arrive_with_the_third_frame(pta, monkeypatch):
+    """A scene builds its escape masks when it is about to render its third frame of the default pipeline (a one-shot render is
+    better off without them); the frame after counts again, the one after that is planned - same bits throughout."""
+    monkeypatch.setenv("PT_ESCAPE_AFTER", "2")
+    host = pta.HostScene.generate_ps5(60000, 3, 8)
+    prof = pta.Profile.make(480, 270, 8, 4)
+    rgb, acc = pta.GpuScene(host).render(prof, pta.Opts.make(flags=pta.PT_FLAG_NO_GRIDS))
+    g = pta.GpuScene(host)
+    seen = []
+    for frame in range(5):
+        rgb2, acc2 = g.render(prof)
+        assert np.array_equal(rgb2, rgb) and np.array_equal(bits(acc2), bits(acc)), frame
+        seen.append(g.info().as_dict())
+    assert [i["escape_prims"] > 0 for i in seen] == [False, False, True, True, True]
+    assert [i["frame_planned"] for i in seen] == [0, 1, 0, 1, 1]

@@ -16,6 +16,8 @@ Prints ms per frame (both pipelines complete) for each mode.
 """
 import argparse, ctypes as C, os, sys, time
 sys.path.insert(0, '.')
+import os
+os.environ.setdefault('PT_ESCAPE_AFTER', '0')   # (a measurement: the escape masks from the scene's first frame, not its third)
 ap = argparse.ArgumentParser()
 ap.add_argument('--shards', type=int, default=8)
 ap.add_argument('--rank', type=int, default=0)

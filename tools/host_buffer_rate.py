@@ -1,6 +1,8 @@
 """pt_render (host buffers: rgb8 + f32 accumulation copied back over PCIe) against pt_render_device at config 3."""
 import sys, time
 sys.path.insert(0, '.')
+import os
+os.environ.setdefault('PT_ESCAPE_AFTER', '0')   # (a measurement: the escape masks from the scene's first frame, not its third)
 import torch
 torch.zeros(1, device='cuda')
 import numpy as np

@@ -2,6 +2,8 @@
 (1920x1080, 64 spp, 4 bounces), origin grids against KD-tree only:  python tools/scene_times.py"""
 import sys, time
 sys.path.insert(0, '.')
+import os
+os.environ.setdefault('PT_ESCAPE_AFTER', '0')   # (a measurement: the escape masks from the scene's first frame, not its third)
 import torch
 torch.zeros(1, device='cuda')
 import __graft_entry__ as e

@@ -2,6 +2,8 @@
     PT_DEBUG_TIMES=1 python tools/shard_launches.py --shards 8 [--rank 0]"""
 import argparse, sys
 sys.path.insert(0, '.')
+import os
+os.environ.setdefault('PT_ESCAPE_AFTER', '0')   # (a measurement: the escape masks from the scene's first frame, not its third)
 import torch
 torch.zeros(1, device='cuda')
 import __graft_entry__ as e

@@ -6,6 +6,8 @@
 and prints every launch with its start offset, duration and the idle gap before it on its stream."""
 import argparse, csv, glob, sys
 sys.path.insert(0, '.')
+import os
+os.environ.setdefault('PT_ESCAPE_AFTER', '0')   # (a measurement: the escape masks from the scene's first frame, not its third)
 ap = argparse.ArgumentParser()
 ap.add_argument('what', choices=['run', 'show'])
 ap.add_argument('dir', nargs='?')

@@ -8,6 +8,8 @@ a PROJECTION for the N-GPU job from one GPU, not an N-GPU measurement.
             (--spp 256 renders a quarter of the samples: the per-rank frame is linear in spp at that size)"""
 import argparse, sys, time
 sys.path.insert(0, '.')
+import os
+os.environ.setdefault('PT_ESCAPE_AFTER', '0')   # (a measurement: the escape masks from the scene's first frame, not its third)
 import torch
 torch.zeros(1, device='cuda')
 import __graft_entry__ as e

@@ -7,6 +7,7 @@ so must the second frame of each pipeline, whose queues are sized by the first f
 import os, sys, time, pathlib
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import numpy as np
+os.environ.setdefault("PT_ESCAPE_AFTER", "0")   # (escape masks from a scene's first frame: the cases render two frames per pipeline)
 import __graft_entry__ as e
 pta = e.load_package()
 orc = e.load_oracle()
