@@ -337,7 +337,9 @@ typedef struct pt_scene_info {
     uint32_t light_grids;     /* lights whose shadow rays use a grid (all or none)    */
     uint64_t grid_refs;       /* list entries of all grids                            */
     float grid_build_seconds;
-    /* escape masks (csrc/pt_escape.h): proofs of misses for the rays that leave a primitive */
+    /* escape masks (csrc/pt_escape.h): proofs of misses for the rays that leave a primitive.  Built on the device when the
+     * scene is about to render its third frame of the default pipeline (PT_ESCAPE_AFTER; a one-shot render is better off
+     * without them) or when pt_scene_escape_copy asks for them: zero until then */
     float escape_build_seconds;
     uint32_t escape_prims;      /* primitives with a mask (the others: all directions "may hit") */
     float escape_clear_fraction; /* of those primitives' 384 direction cells: proven empty */
