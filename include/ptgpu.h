@@ -344,7 +344,7 @@ typedef struct pt_scene_info {
     uint32_t escape_prims;      /* primitives with a mask (the others: all directions "may hit") */
     float escape_clear_fraction; /* of those primitives' 384 direction cells: proven empty */
     /* the path queues of the LAST frame rendered from this scene (csrc/pt_gpu.hip, "frame plan"): the first frame of a
-     * configuration runs in chunks of a fixed budget (PT_QUEUE_GIB, default 8; later frames PT_QUEUE_STEADY_GIB, 16) with every queue as long as the chunk and
+     * configuration runs in chunks of a fixed budget (PT_QUEUE_GIB, default 8; later frames: what their records need, at most PT_QUEUE_STEADY_GIB, 32) with every queue as long as the chunk and
      * counts what each bounce produces; later frames of the same configuration get queues of exactly those lengths */
     uint64_t queue_bytes;        /* device memory held by the queues, hit / shadow records, RNG planes and lists */
     uint32_t queue_chunk_items;  /* work items (pixel samples) per pass over the bounces                        */

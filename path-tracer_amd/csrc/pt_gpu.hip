@@ -1710,10 +1710,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         // (read per frame: the tests change them)
         // First frame 8 GiB: what the CLI pays for in allocation time (path-tracer render of the 500 k-triangle scene, 1080p x 128 spp,
         // render_s with 2 / 4 / 8 / 16 / 64 GiB: 0.121 / 0.095 / 0.080 / 0.136-0.29 / 1.69 s - the frame itself is 0.04-0.05 s).
-        // Later frames 16 GiB: config 3 in one pass (13.8 GiB), the closed room in 5 (32 GiB: 3 passes, 1.7 % faster).
+        // Later frames: what their records need, up to 32 GiB - config 3 takes 14.1 GiB (one pass), the closed room 31.4 GiB in 2
+        // passes (170.2 ms in 5 passes of 12.7 GiB, 165.8 in 2, 164.5 in one of 51.7 GiB), the KD-tree pipeline of config 3 29.7 GiB.
         const double first_gib = [] { const char* e = getenv("PT_QUEUE_GIB"); return e && *e ? atof(e) : 8.0; }();
         const double one_pass_gib = [] { const char* e = getenv("PT_QUEUE_ONE_PASS_GIB"); return e && *e ? atof(e) : 32.0; }();
-        const double steady_gib = [first_gib] { const char* e = getenv("PT_QUEUE_STEADY_GIB"); return e && *e ? atof(e) : std::max(first_gib, 16.0); }();
+        const double steady_gib = [first_gib] { const char* e = getenv("PT_QUEUE_STEADY_GIB"); return e && *e ? atof(e) : std::max(first_gib, 32.0); }();
         static const bool skip_dead_env = [] { const char* e = getenv("PT_PLAN_SKIP"); return !(e && *e && atoi(e) == 0); }();
         skip_dead = skip_dead_env;
         static const bool inline_auto = [] { const char* e = getenv("PT_OG_INLINE_AUTO"); return !(e && *e && atoi(e) == 0); }();
@@ -1742,7 +1743,15 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             for (auto& bt : batches) m_max = std::max<uint32_t>(m_max, (uint32_t)bt.size());
             // (PT_WF_CHUNK caps a chunk; a batch that may be one chunk needs no multiple of ca)
             m_max = std::min<uint32_t>(m_max, (uint64_t)max_items >= items_per_batch ? (uint32_t)((items_per_batch + ca - 1u) / ca) : std::max(1u, max_items / ca));
-            for (uint32_t m = m_max; m >= 1; --m) {
+            // by the number of passes over a batch: m = the fewest first-frame chunks per pass that make that many passes, so the
+            // passes come out even (nine chunks in three passes: 3 + 3 + 3, not 4 + 4 + 1 at a third more memory)
+            uint32_t s_max = 1;
+            for (auto& bt : batches) s_max = std::max<uint32_t>(s_max, (uint32_t)bt.size());
+            uint32_t m_prev = 0;
+            for (uint32_t n_pass = 1; n_pass <= s_max; ++n_pass) {
+                const uint32_t m = (s_max + n_pass - 1u) / n_pass;
+                if (m > m_max || m == m_prev) continue;
+                m_prev = m;
                 uint64_t q1 = 0, q0 = 0, hh = 0, ss = 0, ee = 0;
                 std::vector<uint64_t> tot_q(lv, 0), tot_s(lv, 0);
                 std::vector<uint32_t> last;

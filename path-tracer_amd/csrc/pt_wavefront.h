@@ -245,6 +245,9 @@ PT_D uint32_t wave_fetch(WaveFetch& wf, uint32_t* cursors, uint32_t n, bool need
 #ifndef WF_MIN_WAVES
 #define WF_MIN_WAVES 1   // minimum waves per SIMD the trace/shadow kernels are compiled for
 #endif
+#ifndef WF_ALPHA_WAVES
+#define WF_ALPHA_WAVES WF_MIN_WAVES   // the translucent trace of bounces >= 1: 113 registers, 4 waves (5 by launch bounds: measured below)
+#endif
 #ifndef WF_PRIMARY_WAVES
 #define WF_PRIMARY_WAVES 5   // the bounce-0 trace and the opaque trace are held to 96 registers (they fit without spilling)
 #endif
@@ -857,7 +860,7 @@ PT_D float wf_rng_draw(WfRng& fb, const WfParams& W, const uint32_t* __restrict_
 // place from the screen position k_wf_rng staged (no 64 B/item ray record written and read back).  Translucent
 // scenes keep the number of rng.gen() calls of a path in draws[entry]: the alpha walk below may draw.
 template <bool ALPHA, bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PRIMARY_WAVES : WF_MIN_WAVES) void k_wf_trace(DevScene S, WfParams W,
+__global__ __launch_bounds__(WF_THREADS, (!COUNT && (PRIMARY || !ALPHA)) ? WF_PRIMARY_WAVES : (!COUNT ? WF_ALPHA_WAVES : WF_MIN_WAVES)) void k_wf_trace(DevScene S, WfParams W,
                                                          const uint32_t* __restrict__ tile_offsets,
                                                          float4* __restrict__ queue, uint4* __restrict__ hits,
                                                          const uint4* __restrict__ rng_planes,
