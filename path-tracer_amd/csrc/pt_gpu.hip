@@ -1856,6 +1856,14 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
             cap_q[0] = fs->plan_q[0], cap_q[1] = fs->plan_q[1], cap_h = fs->plan_h, cap_s = fs->plan_s, cap_e = fs->plan_e;
             inline_at = fs->plan_inline;
             inline_at.resize(p.bounces + 2, 0);
+            // test hook (tests/test_frame_plan.py): a plan that is WRONG - every array shorter than its records - so that what
+            // cannot happen does: the kernels must drop the records that do not fit without writing past an array, flag the
+            // frame, and the next call of the configuration must say so
+            if (const char* e = getenv("PT_PLAN_TEST_SHRINK"); e && *e) {
+                const double f = std::min(1.0, std::max(0.01, atof(e)));
+                for (uint32_t* c : {&cap_q[0], &cap_q[1], &cap_s, &cap_e}) *c = std::max<uint32_t>(64u, (uint32_t)(*c * f));
+                cap_h = std::max({(uint32_t)(cap_h * f), cap_q[0], cap_q[1]});
+            }
         }
         if (!exact) {
             cap = cap_a;

@@ -100,3 +100,25 @@ def test_escape_masks_arrive_with_the_third_frame(pta, monkeypatch):
         seen.append(g.info().as_dict())
     assert [i["escape_prims"] > 0 for i in seen] == [False, False, True, True, True]
     assert [i["frame_planned"] for i in seen] == [0, 1, 0, 1, 1]
+
+
+@pytest.mark.parametrize("name,flags", [("head", 0), ("alpha_transparency", 0), ("head", 4)])
+def test_a_wrong_plan_is_reported_not_rendered_silently(pta, scene_cache, monkeypatch, name, flags):
+    """What cannot happen (a queue sized from an earlier frame's counts runs full) made to happen: PT_PLAN_TEST_SHRINK cuts every
+    planned array to 60 %.  The frame must complete without touching memory it does not own, the NEXT call of the configuration
+    must fail loudly, and the one after - counted again - is the right frame."""
+    scene = scene_cache(name)
+    prof = pta.Profile.make(640, 360, 16, 4)
+    opts = pta.Opts.make(flags=flags)
+    g = pta.GpuScene(scene)
+    rgb, acc = g.render(prof, opts)
+    g.render(prof, opts)                                  # planned
+    monkeypatch.setenv("PT_PLAN_TEST_SHRINK", "0.6")
+    g.render(prof, opts)                                  # arrays too short: records dropped, frame flagged (image not checked)
+    monkeypatch.delenv("PT_PLAN_TEST_SHRINK")
+    with pytest.raises(pta.PtError, match="ran full"):
+        g.render(prof, opts)
+    rgb2, acc2 = g.render(prof, opts)                     # first-frame mode again
+    assert np.array_equal(rgb2, rgb) and np.array_equal(bits(acc2), bits(acc))
+    rgb3, acc3 = g.render(prof, opts)                     # and planned again
+    assert np.array_equal(rgb3, rgb) and np.array_equal(bits(acc3), bits(acc)) and g.info().frame_planned == 1
