@@ -1,6 +1,10 @@
 #!/bin/bash
 # PMC counter passes for the integrator kernel (run on the MI355X box via gpurun).
 #   tools/pmc_profile.sh <out_dir_under_gpurun_out> [bench.py args...]
+# For per-launch figures every launch of a kernel should have the same shape: run it with PT_ESCAPE_AFTER=0 (escape masks from the
+# first frame) and PT_QUEUE_GIB=80 (first frame in one pass) in the environment, e.g.
+#   PT_ESCAPE_AFTER=0 PT_QUEUE_GIB=80 bash tools/pmc_profile.sh pmc_r04_j --steps 1 --warmup 2 --no-legacy
+#   python tools/pmc_to_profiles.py gpurun_out/pmc_r04_j r04_j 500000 1920 1080 128 5 1 --scene-flags=8 --frames=5   (4 warm-up frames + 1)
 # Each pass is its own rocprofv3 run with --pmc only (never combined with trace domains other than
 # kernel-trace); tools/pmc_summarize.py folds the CSVs into one JSON for profiles/.
 set -u
