@@ -1928,13 +1928,11 @@ void render_device(const pt_scene& s, const pt_profile& p, const pt_opts* opts_i
         if (fs) {
             // this frame's counts, one line per (batch, chunk): taken every frame (a few KB) - the first frame's feed the plan,
             // the later ones only say whether a queue ran full
-            const uint32_t n_batches = (p.samples + batch - 1u) / batch;
             stats_slots = 0;
             for (uint32_t s0 = 0; s0 < p.samples; s0 += batch) {
                 const uint64_t tot = (uint64_t)blocks64 * 64u * std::min(batch, p.samples - s0);
                 stats_slots += (uint32_t)((tot + cap - 1u) / cap);
             }
-            (void)n_batches;
             if (!fs->pending) {
                 if (fs->n_slots != stats_slots || fs->levels != levels || !fs->host) {
                     if (fs->host) (void)hipHostFree(fs->host);
